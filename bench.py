@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — MaGNet multi-view matching hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One STEP = one pass of the hot path (models/MAGNET.py:146-175) over a batch of `--frames`
+reference frames per GPU, starting from backbone outputs already resident in HBM:
+    pack F-Net features (NCHW fp32 -> channel-last) -> I x [fused sample+warp+score kernel ->
+    G-Net convs -> Gaussian update] -> mask head -> convex upsampling -> list of (B,2,H,W).
+Workload (default C2 = BASELINE.json configs[1]): ScanNet 480x640 input -> 120x160 matching grid,
+V=4 source views, D=64 candidates, F=64, I=1, bf16-stored features, synthetic tensors.
+Frames shard across ranks with no data-path collective (weak scaling: per-GPU work is fixed);
+the only collective is a one-time RCCL broadcast of G-Net/mask-head weights.
+
+Prints ONE JSON line on rank 0 (fields: see the task contract) including
+  roofline      — fused cost-volume kernel: algorithmic bytes per launch / HIP-event time per launch
+  cpu_baseline  — the CPU oracle (oracle/, a restatement of the reference validated against it)
+                  timed on this host's cores on a bounded sample of the same workload (rank 0, N=1)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+from magnet_amd import dist as mdist  # noqa: E402
+from magnet_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+
+
+class _NoBackbone(torch.nn.Module):
+    """D-Net / F-Net are out of scope; the bench starts from their outputs."""
+
+    def forward(self, x):  # pragma: no cover
+        raise RuntimeError("bench.py feeds backbone outputs directly (match_and_refine)")
+
+
+def make_args(wl, iters):
+    from types import SimpleNamespace
+    return SimpleNamespace(MAGNET_sampling_range=3, MAGNET_num_samples=wl.D, MAGNET_mvs_weighting="CW5",
+                           MAGNET_num_train_iter=iters, MAGNET_num_test_iter=iters,
+                           MAGNET_num_source_views=wl.V, dpv_height=wl.h, dpv_width=wl.w, downsample_ratio=4,
+                           FNET_feature_dim=wl.F, DNET_ckpt=None, FNET_ckpt=None, MAGNET_ckpt=None)
+
+
+def device_inputs(wl, B, seed, device):
+    """Synthetic backbone outputs generated directly on the GPU (distributions of SURVEY.md §8d)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    cam = synth.CAMERAS[wl.camera]
+    h, w, V, F = wl.h, wl.w, wl.V, wl.F
+    rnd = lambda *s: torch.randn(*s, generator=g, device=device)
+    uni = lambda lo, hi, *s: torch.rand(*s, generator=g, device=device) * (hi - lo) + lo
+    ref_feat, src_feat = rnd(B, F, h, w), rnd(V * B, F, h, w)
+    gmm = lambda n: torch.cat([uni(*cam["mu"], n, 1, h, w), uni(*cam["sigma"], n, 1, h, w)], dim=1)
+    cpu_gen = torch.Generator().manual_seed(seed)
+    return dict(ref_feat=ref_feat, nghbr_feat=src_feat, ref_gmms=gmm(B), nghbr_gmms=gmm(V * B),
+                x_d3=rnd(B, 256, h, w) * 0.5,
+                nghbr_poses=synth.make_poses(wl.camera, B, V, cpu_gen).to(device),
+                is_valid=torch.ones(B, V, dtype=torch.int32),
+                cam_intrins=synth.make_intrinsics(wl.camera, h, w, B))
+
+
+def cpu_baseline(wl, model_cpu, iters, budget_s=15.0):
+    """Full hot-path step on the host CPU: oracle matcher (all cores, OpenMP) + torch-CPU G-Net +
+    oracle tail/upsample.  Bounded: one frame first, then as many frames as fit ~budget_s."""
+    from oracle import oracle
+    cores = oracle.num_threads()
+    torch.set_num_threads(cores)
+    k = oracle.depth_sampling(3, wl.D)
+    inp = synth.make_inputs(wl, B=1, seed=0)
+    x_d3 = torch.randn(1, 256, wl.h, wl.w, generator=torch.Generator().manual_seed(1)) * 0.5
+
+    def one_frame():
+        gmm = inp["ref_gmms"].clone()
+        with torch.no_grad():
+            for _ in range(iters):
+                cost = torch.from_numpy(oracle.cost_volume_cw(
+                    None, gmm, k, inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"],
+                    inp["is_valid"], inp["cam_intrins"]["intM"], inp["cam_intrins"]["unit_ray_array_2D"], 5.0))
+                raw = model_cpu.g_net.gnet(torch.cat([cost, x_d3], dim=1))
+                gmm = torch.from_numpy(oracle.gaussian_update(raw.numpy(), gmm.numpy()))
+            mask = model_cpu.mask_head(x_d3)
+            oracle.upsample_depth_via_mask(gmm.numpy(), mask.numpy(), 4)
+
+    t0 = time.perf_counter(); one_frame(); t1 = time.perf_counter() - t0      # also warms up
+    n = max(1, min(64, int(budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one_frame()
+    dt = time.perf_counter() - t0
+    # matcher-only rate, for the kernel-level comparison
+    t0 = time.perf_counter()
+    oracle.cost_volume_cw(None, inp["ref_gmms"], k, inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"],
+                          inp["nghbr_poses"], inp["is_valid"], inp["cam_intrins"]["intM"],
+                          inp["cam_intrins"]["unit_ray_array_2D"], 5.0)
+    tm = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "ref-frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frame(s) of {wl.name} ({wl.h}x{wl.w} grid, V={wl.V}, D={wl.D}, I={iters}), "
+                      f"{dt:.1f} s wall; oracle matcher OpenMP x{cores} + torch-CPU G-Net/mask head",
+            "matcher_only_frames_per_s": 1.0 / tm}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C2", choices=sorted(synth.WORKLOADS))
+    ap.add_argument("--frames", type=int, default=0, help="reference frames per GPU per step (0 = auto)")
+    ap.add_argument("--iters", type=int, default=0, help="refinement iterations (0 = workload default)")
+    ap.add_argument("--feat-dtype", default="", choices=["", "fp32", "bf16"])
+    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 generic gather kernel, 2 window/MFMA kernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-only", action="store_true", help="step = the fused cost-volume kernel alone")
+    a = ap.parse_args()
+
+    rank, world, local = mdist.init_from_env()
+    if world != a.gpus and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from magnet_amd import build as mbuild, lib
+    if rank == 0:
+        mbuild.build()
+    mdist.barrier()
+    lib.load()
+    from magnet_amd.homography import CostVolumeCW
+    from magnet_amd.magnet import MAGNET
+
+    wl = synth.WORKLOADS[a.workload]
+    iters = a.iters or wl.iters
+    fdt = a.feat_dtype or wl.feat_dtype
+    # enough frames per step that one launch fills the chip and the working set exceeds the 256 MiB L3
+    B = a.frames or max(1, min(64, int(round(1200e6 / max(wl.algorithmic_bytes(), 1)))))
+    torch.manual_seed(1234)                               # every rank draws its own init; rank 0's wins below
+    model = MAGNET(make_args(wl, iters), d_net=_NoBackbone(), f_net=_NoBackbone(), feat_dtype=fdt)
+    model_cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        import copy
+        model_cpu = copy.deepcopy(model).eval()
+    model = model.to(device).eval()
+    bcast_bytes = mdist.broadcast_module_(model, src=0)   # the one RCCL collective (weights), xGMI
+
+    inp = device_inputs(wl, B, seed=1000 + rank, device=device)
+    k_list = model.k_list
+    ev_pairs = []
+
+    model.matcher_path = a.path
+    if a.kernel_only:
+        matcher = CostVolumeCW(inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"],
+                               inp["is_valid"], inp["cam_intrins"], 5, feat_dtype=fdt, path=a.path)
+        out = torch.empty(B, wl.D, wl.h, wl.w, device=device)
+
+        def step(timed):
+            CostVolumeCW.event_sink = ev_pairs if timed else None   # HIP events around the fused kernel
+            matcher(ref_gmm=inp["ref_gmms"], k_list=k_list, out=out)
+    else:
+        def step(timed):
+            CostVolumeCW.event_sink = ev_pairs if timed else None
+            with torch.no_grad():
+                model.match_and_refine(inp["ref_gmms"], inp["x_d3"], inp["ref_feat"], inp["nghbr_feat"],
+                                       inp["nghbr_gmms"], inp["nghbr_poses"], inp["is_valid"],
+                                       inp["cam_intrins"], mode="test")
+
+    for _ in range(a.warmup):
+        step(False)
+    torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
+    elapsed = mdist.max_over_ranks(time.perf_counter() - t0, device=device)
+
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev_pairs) / max(1, len(ev_pairs))
+    alg_bytes = wl.algorithmic_bytes() * B
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    frames = world * B * a.steps
+
+    if rank == 0:
+        res = {
+            "metric": "ref-frames/sec (640x480, 4 src, 64 cand) + warp-kernel HBM GB/s",
+            "value": frames / elapsed, "unit": "ref-frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if fdt == "fp32" else "f32 (bf16-stored features)",
+            "data": "synthetic",
+            "config": {"workload": f"{wl.name}: {wl.camera} {4 * wl.h}x{4 * wl.w} input -> {wl.h}x{wl.w} matching grid, "
+                                   f"V={wl.V} source views, D={wl.D} candidates, F={wl.F}, I={iters} iteration(s), "
+                                   f"{fdt} feature storage",
+                       "frames_per_gpu_per_step": B, "step": "kernel-only" if a.kernel_only else
+                       "pack + I x (fused cost volume + G-Net(MIOpen) + Gaussian update) + mask head + convex upsample",
+                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; "
+                                      f"one RCCL weight broadcast ({bcast_bytes} B)"},
+            "roofline": {"bound": "hbm", "kernel": "fused sample+warp+score (magnet_cost_volume_cw)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
+                         "launches_timed": len(ev_pairs)},
+            "cost_volume_frames_per_s": B / (kern_ms * 1e-3) if kern_ms > 0 else None,
+        }
+        if model_cpu is not None:
+            res["cpu_baseline"] = cpu_baseline(wl, model_cpu, iters)
+        print(json.dumps(res))
+    mdist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

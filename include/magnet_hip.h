@@ -1,0 +1,106 @@
+/*
+ * magnet_hip.h — C ABI of libmagnet_hip.so, the MI355X (gfx950) implementation of MaGNet's
+ * multi-view matching hot path.  Plain pointers and sizes only; no torch types.  Every entry
+ * point replaces a specific piece of the reference (file:line into baegwangbin/MaGNet):
+ *
+ *   magnet_pack_features     -> the layout hand-off from F-Net's NCHW fp32 output
+ *                               (models/MAGNET.py:142-144) to the kernel's channel-last storage
+ *   magnet_cost_volume_cw    -> homography.est_costvolume_CW  (models/submodules/homography.py:79-121)
+ *                               + _compute_cost_CW            (homography.py:124-161)
+ *                               + the candidate sampling in front of it (models/MAGNET.py:153-156)
+ *   magnet_gaussian_update   -> the element-wise tail of GNET.forward (models/MAGNET.py:60-69)
+ *   magnet_upsample_depth    -> upsample_depth_via_mask       (models/MAGNET.py:15-27)
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers unless the comment says HOST.  Buffers are caller-owned;
+ *     the library never allocates device memory and never synchronises the device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     asynchronous on that stream and re-entrant across streams.
+ *   - Return value: 0 on success; >0 = MAGNET_E_* argument error; <0 = -(hipError_t).  Nothing is
+ *     thrown.  magnet_last_error() returns a thread-local message for the last failing call.
+ *   - Layouts follow the reference: NCHW fp32 for (mu,sigma) maps and the cost volume, source-view
+ *     tensors VIEW-MAJOR (index v*B + b, homography.py:105), rays (B,3,h*w), intM (B,3,3),
+ *     poses (B,V,4,4) row-major [R|t], is_valid (B,V) int32 (1 = use the view, homography.py:97).
+ */
+#ifndef MAGNET_HIP_H
+#define MAGNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAGNET_API __attribute__((visibility("default")))
+
+#define MAGNET_HIP_VERSION 100            /* major*10000 + minor*100 + patch */
+
+enum {                                     /* storage dtype of channel-last feature maps */
+    MAGNET_FEAT_F32  = 0,
+    MAGNET_FEAT_BF16 = 1
+};
+
+enum {                                     /* argument errors (positive return values) */
+    MAGNET_E_NULL     = 1,                 /* a required pointer is NULL */
+    MAGNET_E_DIM      = 2,                 /* a dimension is <= 0 or exceeds a kernel limit */
+    MAGNET_E_DTYPE    = 3,                 /* unknown dtype enum */
+    MAGNET_E_ALIGN    = 4,                 /* a pointer is not 16-byte aligned */
+    MAGNET_E_NODEVICE = 5                  /* no gfx950 device / kernel image not loadable */
+};
+
+#define MAGNET_MAX_CANDIDATES 256          /* D limit of magnet_cost_volume_cw */
+
+/* Arguments of magnet_cost_volume_cw.  Zero-initialise, then fill. */
+typedef struct MagnetCostVolumeArgs {
+    int32_t B, V, F, D, h, w;              /* ref frames, source views, channels (F % 8 == 0), candidates, grid */
+    float   kappa;                         /* consistency threshold: int(weighting.split('CW')[1]), MAGNET.py:159 */
+    int32_t feat_dtype;                    /* MAGNET_FEAT_* of ref_feat_cl / src_feat_cl */
+    const void    *ref_feat_cl;            /* (B,   h, w, F) channel-last  (from magnet_pack_features) */
+    const void    *src_feat_cl;            /* (V*B, h, w, F) channel-last, view-major */
+    const float   *src_gmm;                /* (V*B, 2, h, w) source-view [mu, sigma] */
+    const float   *ref_gmm;                /* (B, 2, h, w) reference [mu, sigma]; used when d_volume == NULL */
+    const double  *k_list;                 /* HOST, D float64 quantile offsets (MAGNET.depth_sampling, MAGNET.py:120-128);
+                                              used when d_volume == NULL: d_j = mu + sigma*(float)k_j */
+    const float   *d_volume;               /* optional (B,D,h,w) explicit candidate depths (the reference's first
+                                              argument); NULL = fused sampling from ref_gmm + k_list */
+    const float   *poses;                  /* (B,V,4,4) relative poses ref->source (utils.data_preprocess) */
+    const int32_t *is_valid;               /* (B,V) */
+    const float   *intM;                   /* (B,3,3) intrinsics at grid resolution */
+    const float   *rays;                   /* (B,3,h*w) unit_ray_array_2D */
+    float         *cost;                   /* OUT (B,D,h,w) fp32; frame b starts at cost + b*cost_batch_stride */
+    int32_t        path;                   /* 0 = auto; 1 = force the generic gather path; 2 = force the
+                                              LDS-window/MFMA path (tiles that do not fit still fall back) */
+    uint32_t      *stats;                  /* optional device uint32[4]: {tiles on the window path, tiles on the
+                                              generic path, 0, 0}, accumulated with atomics; NULL = off */
+    int64_t        cost_batch_stride;      /* elements between consecutive frames of `cost`; 0 = D*h*w (dense).
+                                              Lets the kernel write the first D channels of G-Net's
+                                              (B, D+256, h, w) input directly (models/MAGNET.py:167). */
+} MagnetCostVolumeArgs;
+
+MAGNET_API int magnet_version(void);
+MAGNET_API const char *magnet_last_error(void);
+
+/* Number of gfx950 devices visible to the HIP runtime this library is bound to (0 if none). */
+MAGNET_API int magnet_device_count(void);
+
+/* NCHW fp32 (N,F,h,w) -> channel-last (N,h,w,F) in `out_dtype` (round-to-nearest-even for bf16). */
+MAGNET_API int magnet_pack_features(const float *nchw, void *out_cl, int32_t N, int32_t F, int32_t h, int32_t w,
+                         int32_t out_dtype, void *stream);
+
+/* Consistency-weighted multi-view matching score, all (b, pixel, candidate) in one launch. */
+MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs *args, void *stream);
+
+/* gmm_out[:,0] = mu + o0*sigma ; gmm_out[:,1] = (elu(o1) + 1 + 1e-10)*sigma.   All (B,2,h*w) fp32.
+ * gmm_out may alias gmm_in. */
+MAGNET_API int magnet_gaussian_update(const float *gnet_out, const float *gmm_in, float *gmm_out,
+                           int32_t B, int32_t hw, void *stream);
+
+/* Learned convex upsampling: depth (B,C,h,w), mask (B,9*k*k,h,w) -> out (B,C,k*h,k*w); softmax over
+ * the 9 neighbours, zero padding.  k <= 8. */
+MAGNET_API int magnet_upsample_depth(const float *depth, const float *mask, float *out,
+                          int32_t B, int32_t C, int32_t h, int32_t w, int32_t k, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGNET_HIP_H */

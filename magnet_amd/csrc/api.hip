@@ -1,0 +1,129 @@
+// api.hip — the extern "C" boundary declared in include/magnet_hip.h.  Argument checking, error
+// reporting, kernel selection.  No device allocation, no synchronisation.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "cv_common.hpp"
+
+namespace magnet {
+hipError_t launch_pack(const float*, void*, int, int, int, int, bool, hipStream_t);
+hipError_t launch_gaussian_update(const float*, const float*, float*, int, int, hipStream_t);
+hipError_t launch_upsample(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+}
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char* what) {
+    return fail(-(int)e, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" {
+
+MAGNET_API int magnet_version(void) { return MAGNET_HIP_VERSION; }
+
+MAGNET_API const char* magnet_last_error(void) { return g_err; }
+
+MAGNET_API int magnet_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+MAGNET_API int magnet_pack_features(const float* nchw, void* out_cl, int32_t N, int32_t F, int32_t h, int32_t w,
+                         int32_t out_dtype, void* stream) {
+    if (!nchw || !out_cl) return fail(MAGNET_E_NULL, "magnet_pack_features: NULL pointer");
+    if (N <= 0 || F <= 0 || h <= 0 || w <= 0 || (F % 8) != 0)
+        return fail(MAGNET_E_DIM, "magnet_pack_features: bad dims N=%d F=%d h=%d w=%d (F must be a multiple of 8)", N, F, h, w);
+    if (out_dtype != MAGNET_FEAT_F32 && out_dtype != MAGNET_FEAT_BF16)
+        return fail(MAGNET_E_DTYPE, "magnet_pack_features: unknown dtype %d", out_dtype);
+    if (!aligned16(out_cl)) return fail(MAGNET_E_ALIGN, "magnet_pack_features: out_cl not 16-byte aligned");
+    hipError_t e = magnet::launch_pack(nchw, out_cl, N, F, h, w, out_dtype == MAGNET_FEAT_BF16, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_pack_features launch");
+}
+
+MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream) {
+    if (!a) return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: args is NULL");
+    if (!a->ref_feat_cl || !a->src_feat_cl || !a->src_gmm || !a->poses || !a->is_valid || !a->intM ||
+        !a->rays || !a->cost)
+        return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: a required pointer is NULL");
+    if (!a->d_volume && (!a->ref_gmm || !a->k_list))
+        return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: d_volume is NULL, so ref_gmm and k_list are required");
+    if (a->B <= 0 || a->V <= 0 || a->F <= 0 || a->D <= 0 || a->h <= 0 || a->w <= 0)
+        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: non-positive dimension");
+    if (a->D > MAGNET_MAX_CANDIDATES)
+        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: D=%d exceeds MAGNET_MAX_CANDIDATES=%d", a->D, MAGNET_MAX_CANDIDATES);
+    if ((a->F % 8) != 0) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: F=%d must be a multiple of 8", a->F);
+    if (a->feat_dtype != MAGNET_FEAT_F32 && a->feat_dtype != MAGNET_FEAT_BF16)
+        return fail(MAGNET_E_DTYPE, "magnet_cost_volume_cw: unknown feat_dtype %d", a->feat_dtype);
+    if (!aligned16(a->ref_feat_cl) || !aligned16(a->src_feat_cl))
+        return fail(MAGNET_E_ALIGN, "magnet_cost_volume_cw: feature pointers must be 16-byte aligned");
+    if ((size_t)a->h * a->w * (size_t)a->F * (size_t)a->V * (size_t)a->B >= ((size_t)1 << 40))
+        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: problem too large");
+
+    magnet::CvParams p;
+    memset(&p, 0, sizeof(p));
+    p.B = a->B; p.V = a->V; p.F = a->F; p.D = a->D; p.h = a->h; p.w = a->w;
+    p.tiles_x = (a->w + magnet::TILE_W - 1) / magnet::TILE_W;
+    p.tiles_y = (a->h + magnet::TILE_H - 1) / magnet::TILE_H;
+    if ((size_t)p.tiles_x * p.tiles_y * (size_t)p.B >= 0x7fffffffu)
+        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: grid too large");
+    p.feat_bf16 = (a->feat_dtype == MAGNET_FEAT_BF16);
+    p.kappa = a->kappa;
+    p.ref_feat = a->ref_feat_cl; p.src_feat = a->src_feat_cl; p.src_gmm = a->src_gmm;
+    p.ref_gmm = a->ref_gmm; p.d_volume = a->d_volume; p.poses = a->poses; p.is_valid = a->is_valid;
+    p.intM = a->intM; p.rays = a->rays; p.cost = a->cost; p.stats = a->stats;
+    p.cost_bstride = a->cost_batch_stride ? a->cost_batch_stride : (long long)a->D * a->h * a->w;
+    if (p.cost_bstride < (long long)a->D * a->h * a->w)
+        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: cost_batch_stride smaller than D*h*w");
+    if (!a->d_volume)
+        for (int j = 0; j < a->D; ++j) p.k[j] = (float)a->k_list[j];     // MAGNET.py:155: fp32 scalar multiply
+
+    hipError_t e = hipSuccess;
+    bool handled = false;
+    if (a->path != 1) {
+        e = magnet::launch_cv_window(p, (hipStream_t)stream, &handled);
+        if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw window launch");
+    }
+    if (!handled) {
+        if (a->path == 2) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: window path does not support this shape/dtype");
+        e = magnet::launch_cv_generic(p, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw generic launch");
+    }
+    return 0;
+}
+
+MAGNET_API int magnet_gaussian_update(const float* gnet_out, const float* gmm_in, float* gmm_out, int32_t B, int32_t hw,
+                           void* stream) {
+    if (!gnet_out || !gmm_in || !gmm_out) return fail(MAGNET_E_NULL, "magnet_gaussian_update: NULL pointer");
+    if (B <= 0 || hw <= 0) return fail(MAGNET_E_DIM, "magnet_gaussian_update: bad dims B=%d hw=%d", B, hw);
+    hipError_t e = magnet::launch_gaussian_update(gnet_out, gmm_in, gmm_out, B, hw, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_gaussian_update launch");
+}
+
+MAGNET_API int magnet_upsample_depth(const float* depth, const float* mask, float* out, int32_t B, int32_t C, int32_t h,
+                          int32_t w, int32_t k, void* stream) {
+    if (!depth || !mask || !out) return fail(MAGNET_E_NULL, "magnet_upsample_depth: NULL pointer");
+    if (B <= 0 || h <= 0 || w <= 0 || (C != 1 && C != 2) || (k != 1 && k != 2 && k != 4 && k != 8))
+        return fail(MAGNET_E_DIM, "magnet_upsample_depth: bad dims B=%d C=%d h=%d w=%d k=%d (C in {1,2}, k in {1,2,4,8})", B, C, h, w, k);
+    if (k == 4 && !aligned16(out)) return fail(MAGNET_E_ALIGN, "magnet_upsample_depth: out not 16-byte aligned");
+    hipError_t e = magnet::launch_upsample(depth, mask, out, B, C, h, w, k, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_upsample_depth launch");
+}
+
+}  // extern "C"

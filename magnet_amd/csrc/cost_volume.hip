@@ -1,0 +1,151 @@
+// cost_volume.hip — fused candidate sampling + plane-sweep warp + consistency-weighted matching
+// score for gfx950 (replaces models/MAGNET.py:153-156 + models/submodules/homography.py:79-161).
+//
+// Work decomposition (both kernels): one workgroup = one 16x4 tile of reference pixels of one
+// reference frame; 256 threads = 64 pixels x 4 candidate slices (wave w owns candidates
+// [w*DPT, (w+1)*DPT)), so every wave's 64 lanes are 64 neighbouring pixels: coalesced (mu,sigma),
+// ray and cost-volume accesses, and wave-uniform control flow over (view, candidate).
+//
+//   cv_generic_kernel : for each (pixel, candidate, view) gathers the 4 bilinear taps x F channels
+//                       straight from the channel-last feature maps (L1/L2 served).  Arithmetic is
+//                       the oracle's to the bit (per-channel fused bilerp, ATen cascade sum).  It is
+//                       the fallback for tiles whose source footprint does not fit the LDS window.
+//   (window/MFMA kernel: see cost_volume_window.hip)
+#include "cv_common.hpp"
+
+namespace magnet {
+
+template <typename FeatT> struct FeatChunk;            // one 16-byte load of consecutive channels
+template <> struct FeatChunk<float> {
+    static constexpr int N = 4;
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
+    __device__ __forceinline__ void zero() { v[0] = v[1] = v[2] = v[3] = 0.f; }
+};
+template <> struct FeatChunk<uint16_t> {
+    static constexpr int N = 8;
+    float v[8];
+    __device__ __forceinline__ void load(const uint16_t* p) {
+        const uint4 q = *reinterpret_cast<const uint4*>(p);
+        const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i]     = __uint_as_float(u[i] << 16);
+            v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+};
+
+template <typename FeatT>
+__global__ __launch_bounds__(256) void cv_generic_kernel(const CvParams p) {
+    const int DPT = (p.D + 3) >> 2;                              // candidates per wave (slice)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int slice = tid >> 6;
+    int tile, b;
+    tile_of_block(p, tile, b);
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int x = tx * TILE_W + (lane & (TILE_W - 1));
+    const int y = ty * TILE_H + (lane / TILE_W);
+    const bool inb = (x < p.w) && (y < p.h);
+    const int xc = inb ? x : 0, yc = inb ? y : 0;          // clamp so every lane reads valid memory
+    const size_t hw = (size_t)p.h * p.w;
+    const size_t pix = (size_t)yc * p.w + xc;
+
+    const float r0 = p.rays[((size_t)b * 3 + 0) * hw + pix];
+    const float r1 = p.rays[((size_t)b * 3 + 1) * hw + pix];
+    const float r2 = p.rays[((size_t)b * 3 + 2) * hw + pix];
+    float mu = 0.f, sg = 0.f;
+    if (!p.d_volume) {
+        mu = p.ref_gmm[((size_t)b * 2 + 0) * hw + pix];
+        sg = p.ref_gmm[((size_t)b * 2 + 1) * hw + pix];
+    }
+    const GridConst gc = grid_const(p);
+    const FeatT* __restrict__ ref = reinterpret_cast<const FeatT*>(p.ref_feat) + ((size_t)b * hw + pix) * p.F;
+
+    const float fV = (float)p.V;
+    // candidates outer, views inner: the fp64 view accumulator (homography.py:116,159) is a scalar
+#pragma unroll 1
+    for (int i = 0; i < DPT; ++i) {
+        const int j = slice * DPT + i;
+        if (j >= p.D) break;                                       // wave-uniform
+        float d;
+        if (p.d_volume) d = p.d_volume[((size_t)b * p.D + j) * hw + pix];
+        else { const float sk = sg * p.k[j]; d = mu + sk; }        // MAGNET.py:155 (mul, then add)
+        double acc = 0.0;
+#pragma unroll 1
+        for (int v = 0; v < p.V; ++v) {
+            if (p.is_valid[b * p.V + v] != 1) continue;            // homography.py:97 (wave-uniform)
+            const PixelView pv = make_pixel_view(p.intM + (size_t)b * 9,
+                                                 p.poses + ((size_t)b * p.V + v) * 16, r0, r1, r2);
+            const size_t sidx = (size_t)v * p.B + b;               // view-major, homography.py:105
+            const FeatT* __restrict__ src = reinterpret_cast<const FeatT*>(p.src_feat) + sidx * hw * p.F;
+            const float* __restrict__ smu = p.src_gmm + (sidx * 2 + 0) * hw;
+            const float* __restrict__ ssg = p.src_gmm + (sidx * 2 + 1) * hw;
+            float ix, iy, zw;
+            project(pv, gc, d, ix, iy, zw);
+            const Taps t = make_taps(ix, iy);
+            const bool xa = (t.x0 >= 0) && (t.x0 < p.w), xb = (t.x0 + 1 >= 0) && (t.x0 + 1 < p.w);
+            const bool ya = (t.y0 >= 0) && (t.y0 < p.h), yb = (t.y0 + 1 >= 0) && (t.y0 + 1 < p.h);
+            const bool in_nw = xa && ya, in_ne = xb && ya, in_sw = xa && yb, in_se = xb && yb;
+            // clamp tap addresses (weights of out-of-image taps are applied to zeros)
+            const int x0c = min(max(t.x0, 0), p.w - 1), x1c = min(max(t.x0 + 1, 0), p.w - 1);
+            const int y0c = min(max(t.y0, 0), p.h - 1), y1c = min(max(t.y0 + 1, 0), p.h - 1);
+            const size_t o_nw = (size_t)y0c * p.w + x0c, o_ne = (size_t)y0c * p.w + x1c;
+            const size_t o_sw = (size_t)y1c * p.w + x0c, o_se = (size_t)y1c * p.w + x1c;
+
+            float c = 0.f;
+            if (in_nw || in_ne || in_sw || in_se) {
+                float lvl0 = 0.f, lvl1 = 0.f, lvl2 = 0.f;          // ATen cascade sum (homography.py:155)
+                for (int f0 = 0; f0 < p.F; f0 += FeatChunk<FeatT>::N) {
+                    FeatChunk<FeatT> cr, ca, cb, cc, cd;
+                    cr.load(ref + f0);
+                    if (in_nw) ca.load(src + o_nw * p.F + f0); else ca.zero();
+                    if (in_ne) cb.load(src + o_ne * p.F + f0); else cb.zero();
+                    if (in_sw) cc.load(src + o_sw * p.F + f0); else cc.zero();
+                    if (in_se) cd.load(src + o_se * p.F + f0); else cd.zero();
+#pragma unroll
+                    for (int q = 0; q < FeatChunk<FeatT>::N; ++q) {
+                        const float wv = bilerp(ca.v[q], cb.v[q], cc.v[q], cd.v[q], t);
+                        const float pr = cr.v[q] * wv;
+                        lvl0 = lvl0 + pr;
+                        const int f = f0 + q;
+                        if ((f & 15) == 15) {
+                            lvl1 = lvl1 + lvl0; lvl0 = 0.f;
+                            if ((f & 255) == 255) { lvl2 = lvl2 + lvl1; lvl1 = 0.f; }
+                        }
+                    }
+                }
+                c = (lvl0 + lvl1) + lvl2;
+            }
+            const float mu_w = bilerp(in_nw ? smu[o_nw] : 0.f, in_ne ? smu[o_ne] : 0.f,
+                                      in_sw ? smu[o_sw] : 0.f, in_se ? smu[o_se] : 0.f, t);
+            const float sg_w = bilerp(in_nw ? ssg[o_nw] : 0.f, in_ne ? ssg[o_ne] : 0.f,
+                                      in_sw ? ssg[o_sw] : 0.f, in_se ? ssg[o_se] : 0.f, t);
+            const bool gate = __builtin_fabsf(zw - mu_w) < sg_w * p.kappa;   // homography.py:157-158
+            acc += (double)c * (gate ? 1.0 : 0.0);                           // fp64 view sum, :159,116
+        }
+        if (inb) p.cost[(size_t)b * p.cost_bstride + (size_t)j * hw + pix] = (float)acc / fV;   // :118,120
+    }
+    if (p.stats && tid == 0) atomicAdd(p.stats + 1, 1u);
+}
+
+template <typename FeatT>
+static hipError_t launch_generic_t(const CvParams& p, hipStream_t stream) {
+    const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
+    hipLaunchKernelGGL((cv_generic_kernel<FeatT>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_cv_generic(const CvParams& p, hipStream_t stream) {
+    return p.feat_bf16 ? launch_generic_t<uint16_t>(p, stream) : launch_generic_t<float>(p, stream);
+}
+
+}  // namespace magnet

@@ -1,0 +1,61 @@
+// cv_common.hpp — launch parameters and block->tile mapping shared by the cost-volume kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/magnet_hip.h"
+#include "warp_math.hpp"
+
+namespace magnet {
+
+constexpr int TILE_W = 16;      // reference-pixel tile of one workgroup: 16 x 4 = 64 pixels = 1 wave
+constexpr int TILE_H = 4;
+constexpr int NUM_XCD = 8;      // MI355X: 8 XCDs, block i is dispatched to XCD i % 8
+
+struct CvParams {
+    int B, V, F, D, h, w;
+    int tiles_x, tiles_y;
+    int feat_bf16;
+    float kappa;
+    const void*    ref_feat;
+    const void*    src_feat;
+    const float*   src_gmm;
+    const float*   ref_gmm;
+    const float*   d_volume;
+    const float*   poses;
+    const int32_t* is_valid;
+    const float*   intM;
+    const float*   rays;
+    float*         cost;
+    uint32_t*      stats;
+    long long      cost_bstride;      // elements between frames of `cost`
+    float k[MAGNET_MAX_CANDIDATES];   // (float)k_j, read with wave-uniform indices (scalar loads)
+};
+
+__device__ __forceinline__ GridConst grid_const(const CvParams& p) {
+    GridConst gc;
+    gc.cw = (float)((double)p.w / 2.0);
+    gc.ch = (float)((double)p.h / 2.0);
+    gc.sw = (float)p.w / 2.0f;
+    gc.sh = (float)p.h / 2.0f;
+    return gc;
+}
+
+// XCD-aware block -> (tile, frame) map.  Hardware round-robins consecutive block ids over the 8
+// XCDs; remap so that each XCD (= one private 4 MiB L2) works through one contiguous run of tiles
+// (row-major within a frame), because neighbouring tiles read overlapping source-view footprints.
+// Bijective for any grid size (cdna_hip_programming.md T1).  Speed only — never correctness.
+__device__ __forceinline__ void tile_of_block(const CvParams& p, int& tile, int& b) {
+    const unsigned n = gridDim.x, bid = blockIdx.x;
+    const unsigned q = n / NUM_XCD, r = n % NUM_XCD;
+    const unsigned xcd = bid % NUM_XCD, idx = bid / NUM_XCD;
+    const unsigned start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const unsigned logical = start + idx;
+    const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
+    b = (int)(logical / tiles);
+    tile = (int)(logical % tiles);
+}
+
+hipError_t launch_cv_generic(const CvParams& p, hipStream_t stream);
+hipError_t launch_cv_window(const CvParams& p, hipStream_t stream, bool* handled);
+
+}  // namespace magnet

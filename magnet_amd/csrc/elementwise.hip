@@ -1,0 +1,155 @@
+// elementwise.hip — the HBM-bound helpers around the matcher:
+//   pack_features  : F-Net's NCHW fp32 -> channel-last fp32/bf16 (the cost-volume kernels' storage)
+//   gaussian_update: GNET.forward's tail (models/MAGNET.py:60-69)
+//   upsample_depth : upsample_depth_via_mask (models/MAGNET.py:15-27)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "warp_math.hpp"
+
+namespace magnet {
+
+// ---- pack: (N,F,hw) fp32 -> (N,hw,F) OutT, 64 pixels x FT channels per block through LDS ------
+// Reads are 256-B rows along the pixel axis, writes are 16-B vectors along the channel axis.
+constexpr int PK_PIX = 64;
+template <typename OutT, int FT>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ in, OutT* __restrict__ out,
+                                                    int F, int hw, int blocks_per_img) {
+    __shared__ float tile[FT][PK_PIX + 1];
+    const int n = blockIdx.x / blocks_per_img;
+    const int p0 = (blockIdx.x % blocks_per_img) * PK_PIX;
+    const int f0 = blockIdx.y * FT;
+    const int tid = threadIdx.x, px = tid & 63, cs = tid >> 6;
+    const int p = p0 + px;
+    for (int c = cs; c < FT; c += 4) {
+        const int f = f0 + c;
+        tile[c][px] = (p < hw && f < F) ? in[((size_t)n * F + f) * hw + p] : 0.f;
+    }
+    __syncthreads();
+    constexpr int VEC = 16 / sizeof(OutT);           // channels per 16-byte store
+    constexpr int VPP = FT / VEC;                    // vectors per pixel
+    for (int i = tid; i < PK_PIX * VPP; i += 256) {
+        const int q = i / VPP, vc = (i % VPP) * VEC;
+        const int pq = p0 + q;
+        if (pq >= hw || f0 + vc >= F) continue;
+        OutT* dst = out + ((size_t)n * hw + pq) * F + f0 + vc;
+        if constexpr (sizeof(OutT) == 4) {
+            float4 o = make_float4(tile[vc][q], tile[vc + 1][q], tile[vc + 2][q], tile[vc + 3][q]);
+            *reinterpret_cast<float4*>(dst) = o;
+        } else {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                w[k] = (uint32_t)f32_to_bf16_rne(tile[vc + 2 * k][q]) |
+                       ((uint32_t)f32_to_bf16_rne(tile[vc + 2 * k + 1][q]) << 16);
+            *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
+hipError_t launch_pack(const float* in, void* out, int N, int F, int h, int w, bool bf16, hipStream_t s) {
+    const int hw = h * w;
+    const int bpi = (hw + PK_PIX - 1) / PK_PIX;
+    constexpr int FT = 64;
+    const dim3 grid((unsigned)(N * bpi), (unsigned)((F + FT - 1) / FT)), block(256);
+    if (bf16) hipLaunchKernelGGL((pack_kernel<uint16_t, FT>), grid, block, 0, s, in, (uint16_t*)out, F, hw, bpi);
+    else      hipLaunchKernelGGL((pack_kernel<float, FT>),    grid, block, 0, s, in, (float*)out, F, hw, bpi);
+    return hipGetLastError();
+}
+
+// ---- gaussian update ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gaussian_update_kernel(const float* __restrict__ o,
+                                                               const float* __restrict__ g,
+                                                               float* __restrict__ out, int B, int hw) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * hw) return;
+    const size_t b = i / hw, p = i % hw;
+    const float mu0 = g[(b * 2 + 0) * hw + p], sg0 = g[(b * 2 + 1) * hw + p];
+    const float o0 = o[(b * 2 + 0) * hw + p], o1 = o[(b * 2 + 1) * hw + p];
+    const float mu1 = mu0 + (o0 * sg0);                                 // MAGNET.py:67
+    const float e = (o1 > 0.f) ? o1 : expm1f(o1);                       // F.elu
+    const float sg1 = ((e + 1.0f) + 1e-10f) * sg0;                      // MAGNET.py:68
+    out[(b * 2 + 0) * hw + p] = mu1;
+    out[(b * 2 + 1) * hw + p] = sg1;
+}
+
+hipError_t launch_gaussian_update(const float* o, const float* g, float* out, int B, int hw, hipStream_t s) {
+    const size_t n = (size_t)B * hw;
+    hipLaunchKernelGGL(gaussian_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, o, g, out, B, hw);
+    return hipGetLastError();
+}
+
+// ---- learned convex upsampling -------------------------------------------------------------------
+// One thread per coarse pixel; lanes run along x so every mask-plane read is coalesced; the k
+// sub-pixels of one output row are stored as one contiguous run per lane (16 B for k = 4).
+template <int K, int C>
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ depth,
+                                                        const float* __restrict__ mask,
+                                                        float* __restrict__ out, int B, int h, int w) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (x >= w || y >= h) return;
+    const size_t hw = (size_t)h * w;
+    float nb[C][9];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int n = 0; n < 9; ++n) {
+            const int yy = y + n / 3 - 1, xx = x + n % 3 - 1;          // F.unfold(depth,[3,3],padding=1)
+            nb[c][n] = (yy >= 0 && yy < h && xx >= 0 && xx < w)
+                           ? depth[((size_t)b * C + c) * hw + (size_t)yy * w + xx] : 0.f;
+        }
+    const float* m = mask + (size_t)b * 9 * K * K * hw + (size_t)y * w + x;
+    const size_t W2 = (size_t)w * K;
+#pragma unroll 1
+    for (int i = 0; i < K; ++i) {
+        float o[C][K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float mv[9], mx = -3.4e38f;
+#pragma unroll
+            for (int n = 0; n < 9; ++n) { mv[n] = m[(size_t)(n * K * K + i * K + j) * hw]; mx = fmaxf(mx, mv[n]); }
+            float den = 0.f;
+#pragma unroll
+            for (int n = 0; n < 9; ++n) { mv[n] = __expf(mv[n] - mx); den += mv[n]; }
+            const float inv = 1.0f / den;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int n = 0; n < 9; ++n) a += (mv[n] * inv) * nb[c][n];
+                o[c][j] = a;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float* dst = out + (((size_t)b * C + c) * h * K + (size_t)y * K + i) * W2 + (size_t)x * K;
+            if constexpr (K == 4) *reinterpret_cast<float4*>(dst) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+            else {
+#pragma unroll
+                for (int j = 0; j < K; ++j) dst[j] = o[c][j];
+            }
+        }
+    }
+}
+
+template <int K>
+static hipError_t launch_up_k(const float* d, const float* m, float* o, int B, int C, int h, int w, hipStream_t s) {
+    const dim3 grid((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)B), block(256);
+    if (C == 2)      hipLaunchKernelGGL((upsample_kernel<K, 2>), grid, block, 0, s, d, m, o, B, h, w);
+    else if (C == 1) hipLaunchKernelGGL((upsample_kernel<K, 1>), grid, block, 0, s, d, m, o, B, h, w);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_upsample(const float* d, const float* m, float* o, int B, int C, int h, int w, int k, hipStream_t s) {
+    switch (k) {
+        case 1: return launch_up_k<1>(d, m, o, B, C, h, w, s);
+        case 2: return launch_up_k<2>(d, m, o, B, C, h, w, s);
+        case 4: return launch_up_k<4>(d, m, o, B, C, h, w, s);
+        case 8: return launch_up_k<8>(d, m, o, B, C, h, w, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace magnet

@@ -1,0 +1,85 @@
+"""Multi-GPU plumbing for the matching path.
+
+Reference frames are independent (homography.py:88 has no cross-batch state), so the path shards
+embarrassingly: one process per GPU, each rank owns a contiguous range of reference frames and runs
+the whole loop locally.  The only collective on the inference path is a ONE-TIME broadcast of the
+shared trainable weights (G-Net, mask head — and F-Net/D-Net when present) from rank 0; over xGMI
+that is one flat bucket per dtype (a few MB) rather than one message per parameter.  Timing
+reductions (max over ranks) and optional metric gathers use tiny all_reduce / all_gather calls.
+backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous, balanced [lo, hi) range of reference frames owned by `rank`."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+@torch.no_grad()
+def broadcast_module_(module: torch.nn.Module, src: int = 0):
+    """Broadcast all parameters and buffers of `module` from rank `src`, one flat bucket per dtype."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    by_dtype: dict = {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    nbytes = 0
+    for (_, _), tensors in by_dtype.items():
+        flat = torch.cat([t.detach().reshape(-1) for t in tensors])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+        nbytes += flat.numel() * flat.element_size()
+    return nbytes
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device=None) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

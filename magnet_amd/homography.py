@@ -1,0 +1,121 @@
+"""Host mirror of the reference's `models/submodules/homography.py` for the consistency-weighted
+matcher.  Same function name, argument order and meaning as the reference so that
+`import magnet_amd.homography as homography` drops in at models/MAGNET.py:160-164; all compute goes
+through the C ABI (magnet_amd.lib -> libmagnet_hip.so).  No CPU path exists here.
+
+Two entry points:
+
+* `est_costvolume_CW(d_volume, ref_feat, nghbr_feat, ref_gmms, nghbr_gmms, R, t, is_valid,
+  cam_intrins, thres)` — the reference signature (homography.py:79-80).  Packs the NCHW features
+  on every call, exactly as stateless as the reference.
+* `CostVolumeCW` — the per-forward state the MAGNET loop uses: features are packed ONCE per
+  forward (they do not change across refinement iterations, MAGNET.py:142-144 vs :151), intrinsics /
+  validity live on the device, candidates are sampled inside the kernel from (mu, sigma, k_list).
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+
+from . import lib
+
+# cam_intrins arrive as CPU tensors (the reference re-uploads them per call and per batch item,
+# homography.py:89-90).  Cache device copies keyed on the CPU tensor's storage + version.
+_INTRINS_CACHE: dict = {}
+_VALID_CACHE: dict = {}
+
+
+def _to_device_cached(t: torch.Tensor, device, dtype, cache: dict):
+    if t.is_cuda:
+        return t.to(device=device, dtype=dtype).contiguous()
+    key = (t.data_ptr(), t._version, tuple(t.shape), str(device), dtype)
+    hit = cache.get(key)
+    if hit is not None and hit[0]() is t:
+        return hit[1]
+    if len(cache) > 64:
+        cache.clear()
+    d = t.to(device=device, dtype=dtype).contiguous()
+    cache[key] = (weakref.ref(t), d)
+    return d
+
+
+def _valid_to_device(is_valid: torch.Tensor, device):
+    if is_valid.is_cuda:
+        return is_valid.to(device=device, dtype=torch.int32).contiguous()
+    key = (bytes(is_valid.to(torch.int32).contiguous().numpy().tobytes()), tuple(is_valid.shape), str(device))
+    d = _VALID_CACHE.get(key)
+    if d is None:
+        if len(_VALID_CACHE) > 256:
+            _VALID_CACHE.clear()
+        d = is_valid.to(device=device, dtype=torch.int32).contiguous()
+        _VALID_CACHE[key] = d
+    return d
+
+
+def _poses_from_Rt(R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    B, V = R.shape[:2]
+    poses = torch.zeros((B, V, 4, 4), dtype=torch.float32, device=R.device)
+    poses[:, :, :3, :3] = R
+    poses[:, :, :3, 3] = t
+    poses[:, :, 3, 3] = 1.0
+    return poses
+
+
+class CostVolumeCW:
+    """Per-forward matcher state: packed features + device-side geometry.
+
+    feat_dtype: 'fp32' (bit-faithful storage) or 'bf16' (features rounded once to bf16, fp32 math —
+    BASELINE config C2; parity is defined against the oracle fed the same rounded features)."""
+
+    # When set to a list, every launch appends a (start, end) pair of HIP events recorded on the launch
+    # stream around the fused kernel (bench.py's live per-launch timing for the roofline figure).
+    event_sink = None
+
+    def __init__(self, ref_feat, nghbr_feat, nghbr_gmms, nghbr_poses, is_valid, cam_intrins, thres,
+                 feat_dtype="fp32", path: int = 0):
+        dev = ref_feat.device
+        if not ref_feat.is_cuda:
+            raise lib.MagnetError("CostVolumeCW: features must be on the GPU (no CPU fallback)")
+        self.fe = lib.feat_enum(feat_dtype)
+        self.B, self.F, self.h, self.w = ref_feat.shape
+        self.V = nghbr_feat.shape[0] // self.B
+        self.ref_cl = lib.pack_features(ref_feat.detach().float().contiguous(), self.fe)
+        self.src_cl = lib.pack_features(nghbr_feat.detach().float().contiguous(), self.fe)
+        self.src_gmm = nghbr_gmms.detach().float().contiguous()
+        self.poses = nghbr_poses.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self.is_valid = _valid_to_device(is_valid, dev)
+        self.intM = _to_device_cached(cam_intrins["intM"], dev, torch.float32, _INTRINS_CACHE)
+        self.rays = _to_device_cached(cam_intrins["unit_ray_array_2D"], dev, torch.float32, _INTRINS_CACHE)
+        self.kappa = float(thres)
+        self.path = path
+
+    def __call__(self, ref_gmm=None, k_list=None, d_volume=None, out=None, stats=None):
+        if d_volume is not None:
+            d_volume = d_volume.detach().float().contiguous()
+        if ref_gmm is not None:
+            ref_gmm = ref_gmm.detach().float().contiguous()
+        sink = CostVolumeCW.event_sink
+        if sink is not None:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        res = lib.cost_volume_cw(self.ref_cl, self.src_cl, self.src_gmm, self.poses, self.is_valid,
+                                 self.intM, self.rays, self.kappa, ref_gmm=ref_gmm, k_list=k_list,
+                                 d_volume=d_volume, out=out, path=self.path, stats=stats)
+        if sink is not None:
+            e1.record()
+            sink.append((e0, e1))
+        return res
+
+
+def est_costvolume_CW(d_volume, ref_feat, nghbr_feat, ref_gmms, nghbr_gmms,
+                      R, t, is_valid, cam_intrins, thres, feat_dtype="fp32"):
+    """Drop-in for homography.est_costvolume_CW (reference homography.py:79-121).
+
+    d_volume (B,D,h,w); ref_feat (B,F,h,w); nghbr_feat (V*B,F,h,w) view-major; ref_gmms is accepted
+    and ignored exactly like the reference (never read there); nghbr_gmms (V*B,2,h,w); R (B,V,3,3);
+    t (B,V,3); is_valid (B,V) int (CPU or GPU); cam_intrins dict of (CPU or GPU) tensors; thres = kappa.
+    Returns (B,D,h,w) fp32 on ref_feat.device."""
+    poses = _poses_from_Rt(R.detach().float(), t.detach().float())
+    cv = CostVolumeCW(ref_feat, nghbr_feat, nghbr_gmms, poses, is_valid, cam_intrins, thres, feat_dtype)
+    return cv(d_volume=d_volume)

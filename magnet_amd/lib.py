@@ -1,0 +1,219 @@
+"""ctypes binding of libmagnet_hip.so (the C ABI in include/magnet_hip.h).
+
+torch is used for device memory and streams only: every call passes `tensor.data_ptr()` and the
+current HIP stream through the C boundary.  There is NO CPU fallback — if the library is missing,
+or an argument lives on the CPU, the call raises.  torch must be imported before the library is
+loaded so that libmagnet_hip.so binds to the same libamdhip64 (same SONAME) torch has loaded.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmagnet_hip.so")
+
+FEAT_F32, FEAT_BF16 = 0, 1
+MAX_CANDIDATES = 256
+
+API_SYMBOLS = ("magnet_version", "magnet_last_error", "magnet_device_count", "magnet_pack_features",
+               "magnet_cost_volume_cw", "magnet_gaussian_update", "magnet_upsample_depth")
+
+
+class MagnetError(RuntimeError):
+    pass
+
+
+class MagnetCostVolumeArgs(ctypes.Structure):
+    """Mirror of `struct MagnetCostVolumeArgs` (include/magnet_hip.h)."""
+    _fields_ = [
+        ("B", ctypes.c_int32), ("V", ctypes.c_int32), ("F", ctypes.c_int32), ("D", ctypes.c_int32),
+        ("h", ctypes.c_int32), ("w", ctypes.c_int32),
+        ("kappa", ctypes.c_float), ("feat_dtype", ctypes.c_int32),
+        ("ref_feat_cl", ctypes.c_void_p), ("src_feat_cl", ctypes.c_void_p),
+        ("src_gmm", ctypes.c_void_p), ("ref_gmm", ctypes.c_void_p),
+        ("k_list", ctypes.c_void_p), ("d_volume", ctypes.c_void_p),
+        ("poses", ctypes.c_void_p), ("is_valid", ctypes.c_void_p),
+        ("intM", ctypes.c_void_p), ("rays", ctypes.c_void_p),
+        ("cost", ctypes.c_void_p),
+        ("path", ctypes.c_int32), ("stats", ctypes.c_void_p),
+        ("cost_batch_stride", ctypes.c_int64),
+    ]
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library (once).  Raises MagnetError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MagnetError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m magnet_amd.build` "
+            "(or __graft_entry__.build()). magnet_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    I, P = ctypes.c_int32, ctypes.c_void_p
+    lib.magnet_version.restype = ctypes.c_int
+    lib.magnet_last_error.restype = ctypes.c_char_p
+    lib.magnet_device_count.restype = ctypes.c_int
+    lib.magnet_pack_features.restype = ctypes.c_int
+    lib.magnet_pack_features.argtypes = [P, P, I, I, I, I, I, P]
+    lib.magnet_cost_volume_cw.restype = ctypes.c_int
+    lib.magnet_cost_volume_cw.argtypes = [ctypes.POINTER(MagnetCostVolumeArgs), P]
+    lib.magnet_gaussian_update.restype = ctypes.c_int
+    lib.magnet_gaussian_update.argtypes = [P, P, P, I, I, P]
+    lib.magnet_upsample_depth.restype = ctypes.c_int
+    lib.magnet_upsample_depth.argtypes = [P, P, P, I, I, I, I, I, P]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().magnet_last_error().decode("utf-8", "replace")
+        raise MagnetError(f"{what} failed (rc={rc}): {msg}")
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise MagnetError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise MagnetError(f"{name} is on {t.device}; magnet_amd runs on the GPU only (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise MagnetError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise MagnetError(f"{name} must be contiguous")
+    return t
+
+
+def _stream(t: torch.Tensor) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def feat_torch_dtype(feat_dtype: int):
+    return torch.bfloat16 if feat_dtype == FEAT_BF16 else torch.float32
+
+
+def feat_enum(dtype) -> int:
+    if dtype in (torch.bfloat16, "bf16", "bfloat16", FEAT_BF16):
+        return FEAT_BF16
+    if dtype in (torch.float32, "fp32", "float32", FEAT_F32):
+        return FEAT_F32
+    raise MagnetError(f"unsupported feature storage dtype {dtype!r} (fp32 or bf16)")
+
+
+def pack_features(feat_nchw: torch.Tensor, feat_dtype: int = FEAT_F32, out: torch.Tensor | None = None):
+    """(N,F,h,w) fp32 NCHW -> (N,h,w,F) channel-last in fp32 or bf16 storage."""
+    x = _dev(feat_nchw, "feat_nchw", torch.float32)
+    N, F, h, w = x.shape
+    if out is None:
+        out = torch.empty((N, h, w, F), dtype=feat_torch_dtype(feat_dtype), device=x.device)
+    else:
+        _dev(out, "out", feat_torch_dtype(feat_dtype))
+        if tuple(out.shape) != (N, h, w, F):
+            raise MagnetError(f"out has shape {tuple(out.shape)}, expected {(N, h, w, F)}")
+    with torch.cuda.device(x.device):
+        _check(load().magnet_pack_features(x.data_ptr(), out.data_ptr(), N, F, h, w, feat_dtype, _stream(x)),
+               "magnet_pack_features")
+    return out
+
+
+def cost_volume_cw(ref_feat_cl, src_feat_cl, src_gmm, poses, is_valid, intM, rays, kappa,
+                   ref_gmm=None, k_list=None, d_volume=None, out=None, path: int = 0, stats=None):
+    """Launch the fused matching kernel.  All tensors on one GPU; see MagnetCostVolumeArgs.
+
+    ref_feat_cl (B,h,w,F) / src_feat_cl (V*B,h,w,F): fp32 or bf16 channel-last (pack_features).
+    src_gmm (V*B,2,h,w), poses (B,V,4,4), is_valid (B,V) int32, intM (B,3,3), rays (B,3,h*w).
+    Either d_volume (B,D,h,w) or (ref_gmm (B,2,h,w), k_list: sequence of D python floats)."""
+    r = _dev(ref_feat_cl, "ref_feat_cl")
+    s = _dev(src_feat_cl, "src_feat_cl", r.dtype)
+    fe = feat_enum(r.dtype)
+    B, h, w, F = r.shape
+    if s.shape[0] % B != 0 or tuple(s.shape[1:]) != (h, w, F):
+        raise MagnetError(f"src_feat_cl shape {tuple(s.shape)} does not match ref_feat_cl {tuple(r.shape)}")
+    V = s.shape[0] // B
+    a = MagnetCostVolumeArgs()
+    a.B, a.V, a.F, a.h, a.w = B, V, F, h, w
+    a.kappa = float(kappa)
+    a.feat_dtype = fe
+    a.ref_feat_cl, a.src_feat_cl = r.data_ptr(), s.data_ptr()
+    g = _dev(src_gmm, "src_gmm", torch.float32)
+    if tuple(g.shape) != (V * B, 2, h, w):
+        raise MagnetError(f"src_gmm shape {tuple(g.shape)}, expected {(V * B, 2, h, w)}")
+    a.src_gmm = g.data_ptr()
+    keep = [r, s, g]
+    kbuf = None
+    if d_volume is not None:
+        dv = _dev(d_volume, "d_volume", torch.float32)
+        if dv.dim() != 4 or dv.shape[0] != B or tuple(dv.shape[2:]) != (h, w):
+            raise MagnetError(f"d_volume shape {tuple(dv.shape)}, expected (B,D,h,w) = ({B},D,{h},{w})")
+        D = dv.shape[1]
+        a.d_volume = dv.data_ptr(); keep.append(dv)
+    else:
+        if ref_gmm is None or k_list is None:
+            raise MagnetError("need d_volume, or ref_gmm and k_list")
+        rg = _dev(ref_gmm, "ref_gmm", torch.float32)
+        if tuple(rg.shape) != (B, 2, h, w):
+            raise MagnetError(f"ref_gmm shape {tuple(rg.shape)}, expected {(B, 2, h, w)}")
+        D = len(k_list)
+        kbuf = (ctypes.c_double * D)(*[float(k) for k in k_list])
+        a.ref_gmm = rg.data_ptr(); a.k_list = ctypes.addressof(kbuf); keep.append(rg)
+    a.D = D
+    po = _dev(poses, "poses", torch.float32); iv = _dev(is_valid, "is_valid", torch.int32)
+    K = _dev(intM, "intM", torch.float32); ry = _dev(rays, "rays", torch.float32)
+    if tuple(po.shape) != (B, V, 4, 4) or tuple(iv.shape) != (B, V) or tuple(K.shape) != (B, 3, 3) \
+            or tuple(ry.shape) != (B, 3, h * w):
+        raise MagnetError("poses/is_valid/intM/rays shape mismatch: "
+                          f"{tuple(po.shape)} {tuple(iv.shape)} {tuple(K.shape)} {tuple(ry.shape)}")
+    a.poses, a.is_valid, a.intM, a.rays = po.data_ptr(), iv.data_ptr(), K.data_ptr(), ry.data_ptr()
+    if out is None:
+        out = torch.empty((B, D, h, w), dtype=torch.float32, device=r.device)
+    else:
+        # `out` may be the leading-D-channel slice of a larger (B, D+C, h, w) buffer (G-Net's input)
+        if not out.is_cuda or out.dtype != torch.float32 or tuple(out.shape) != (B, D, h, w):
+            raise MagnetError(f"out must be a float32 GPU tensor of shape {(B, D, h, w)}")
+        if out.stride()[1:] != (h * w, w, 1) or (B > 1 and out.stride(0) < D * h * w):
+            raise MagnetError(f"out strides {out.stride()} unsupported (need dense (D,h,w) frames)")
+        a.cost_batch_stride = out.stride(0) if B > 1 else 0
+    a.cost = out.data_ptr()
+    a.path = int(path)
+    if stats is not None:
+        a.stats = _dev(stats, "stats").data_ptr()
+    for t in (s, g, po, iv, K, ry):
+        if t.device != r.device:
+            raise MagnetError("all tensors must be on the same device")
+    with torch.cuda.device(r.device):
+        _check(load().magnet_cost_volume_cw(ctypes.byref(a), _stream(r)), "magnet_cost_volume_cw")
+    return out
+
+
+def gaussian_update(gnet_out, gmm_in, out=None):
+    """(B,2,h,w) G-Net output + previous [mu,sigma] -> new [mu,sigma] (MAGNET.py:60-69)."""
+    o = _dev(gnet_out, "gnet_out", torch.float32); g = _dev(gmm_in, "gmm_in", torch.float32)
+    if o.shape != g.shape or o.dim() != 4 or o.shape[1] != 2:
+        raise MagnetError(f"gaussian_update: shapes {tuple(o.shape)} / {tuple(g.shape)}, expected (B,2,h,w)")
+    if out is None:
+        out = torch.empty_like(g)
+    B, _, h, w = g.shape
+    with torch.cuda.device(g.device):
+        _check(load().magnet_gaussian_update(o.data_ptr(), g.data_ptr(), _dev(out, "out", torch.float32).data_ptr(),
+                                             B, h * w, _stream(g)), "magnet_gaussian_update")
+    return out
+
+
+def upsample_depth(depth, up_mask, k: int, out=None):
+    """Learned convex upsampling (MAGNET.py:15-27): (B,C,h,w),(B,9*k*k,h,w) -> (B,C,k*h,k*w)."""
+    d = _dev(depth, "depth", torch.float32); m = _dev(up_mask, "up_mask", torch.float32)
+    B, C, h, w = d.shape
+    if tuple(m.shape) != (B, 9 * k * k, h, w):
+        raise MagnetError(f"up_mask shape {tuple(m.shape)}, expected {(B, 9 * k * k, h, w)}")
+    if out is None:
+        out = torch.empty((B, C, k * h, k * w), dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device):
+        _check(load().magnet_upsample_depth(d.data_ptr(), m.data_ptr(), _dev(out, "out", torch.float32).data_ptr(),
+                                            B, C, h, w, k, _stream(d)), "magnet_upsample_depth")
+    return out

@@ -1,0 +1,174 @@
+"""Host mirror of the reference's `models/MAGNET.py`: same class names, constructor argument,
+`forward(ref_img, nghbr_imgs, nghbr_poses, is_valid, cam_intrins, mode)` signature, return value
+(list of (B,2,H,W) tensors) and state_dict keys (`g_net.gnet.*`, `mask_head.*`, `d_net.*`, `f_net.*`).
+
+What runs where:
+  * candidate sampling + warping + consistency-weighted score  -> HIP kernel (lib.cost_volume_cw)
+  * G-Net / mask-head convolutions                              -> torch (MIOpen) — SURVEY.md §8 N1 is next
+  * Gaussian update tail, convex upsampling                     -> HIP kernels (lib.gaussian_update/upsample_depth)
+  * D-Net / F-Net                                               -> caller-provided modules (out of scope, §2 #5-6)
+"""
+from __future__ import annotations
+
+import math
+from statistics import NormalDist
+
+import torch
+import torch.nn as nn
+
+from . import lib
+from .homography import CostVolumeCW
+
+
+def depth_sampling(sampling_range, n_samples) -> list:
+    """k_j = mid-points of the N(0,1) quantile bins over +-sampling_range
+    (reference MAGNET.depth_sampling, models/MAGNET.py:120-128; float64 on the host)."""
+    P_total = math.erf(sampling_range / math.sqrt(2.0))
+    nd = NormalDist()
+    k = [nd.inv_cdf((1 - P_total) / 2 + (i / n_samples) * P_total) for i in range(n_samples + 1)]
+    return [(k[i + 1] + k[i]) / 2 for i in range(n_samples)]
+
+
+def upsample_depth_via_mask(depth, up_mask, k):
+    """Learned convex upsampling (reference models/MAGNET.py:15-27) on the HIP kernel."""
+    return lib.upsample_depth(depth.detach().float().contiguous(), up_mask.detach().float().contiguous(), int(k))
+
+
+def load_checkpoint(fpath, model):
+    """Same behaviour as the reference's loader (models/MAGNET.py:31-43): accepts {'model': sd} or a
+    bare state_dict, strips a leading 'module.'."""
+    ckpt = torch.load(fpath, map_location="cpu")
+    if "model" in ckpt:
+        ckpt = ckpt["model"]
+    load_dict = {}
+    for k, v in ckpt.items():
+        load_dict[k.replace("module.", "") if k.startswith("module.") else k] = v
+    model.load_state_dict(load_dict)
+    return model
+
+
+class GNET(nn.Module):
+    """conv3x3(ch_in->128)-ReLU-1x1-ReLU-1x1-ReLU-1x1(->2), then the Gaussian update
+    (reference models/MAGNET.py:47-70).  Inference (no_grad) uses the fused HIP tail; under autograd
+    the tail is evaluated with torch ops so g_net stays trainable like the reference's."""
+
+    def __init__(self, ch_in, ch_out=2):
+        super().__init__()
+        h_dim = 128
+        self.gnet = nn.Sequential(
+            nn.Conv2d(ch_in, h_dim, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(h_dim, h_dim, 1), nn.ReLU(inplace=True),
+            nn.Conv2d(h_dim, h_dim, 1), nn.ReLU(inplace=True),
+            nn.Conv2d(h_dim, ch_out, 1))
+
+    def forward(self, cost_volume, ref_gmm):
+        d_output = self.gnet(cost_volume)
+        if torch.is_grad_enabled() and d_output.requires_grad:
+            mu_0, sigma_0 = torch.split(ref_gmm, 1, dim=1)
+            mu_1, sigma_1 = torch.split(d_output, 1, dim=1)
+            mu_new = mu_0 + (mu_1 * sigma_0)
+            sigma_new = (nn.functional.elu(sigma_1) + 1.0 + 1e-10) * sigma_0
+            return torch.cat([mu_new, sigma_new], dim=1)
+        return lib.gaussian_update(d_output.float().contiguous(), ref_gmm.detach().float().contiguous())
+
+
+class MAGNET(nn.Module):
+    """Drop-in for the reference's MAGNET (models/MAGNET.py:73-175).
+
+    `args` carries the same fields (MAGNET_sampling_range, MAGNET_num_samples, MAGNET_mvs_weighting,
+    MAGNET_num_train_iter, MAGNET_num_test_iter, dpv_height, dpv_width, downsample_ratio).  The frozen
+    backbones are out of this build's scope: pass them as `d_net` (img -> ((N,2,h,w), (N,256,h,w))) and
+    `f_net` (img -> (N,F,h,w)); if omitted, the reference's own `models.DNET.DNET` / `models.FNET.FNET`
+    are imported when the caller has them on sys.path (they need torch.hub / checkpoints).
+    `feat_dtype`: 'fp32' or 'bf16' storage of F-Net features inside the matcher."""
+
+    def __init__(self, args, d_net: nn.Module | None = None, f_net: nn.Module | None = None,
+                 feat_dtype: str = "fp32"):
+        super().__init__()
+        self.args = args
+        if d_net is None or f_net is None:
+            try:
+                from models.DNET import DNET      # the user's MaGNet checkout
+                from models.FNET import FNET
+            except Exception as e:  # pragma: no cover
+                raise lib.MagnetError(
+                    "MAGNET needs the frozen D-Net and F-Net: pass d_net=/f_net= modules, or put the "
+                    "MaGNet repository on sys.path so models.DNET / models.FNET import") from e
+            if d_net is None:
+                d_net = DNET(args, dnet=False)
+                if getattr(args, "DNET_ckpt", None):
+                    d_net = load_checkpoint(args.DNET_ckpt, d_net)
+            if f_net is None:
+                f_net = FNET(args)
+                if getattr(args, "FNET_ckpt", None):
+                    f_net = load_checkpoint(args.FNET_ckpt, f_net)
+        self.d_net = d_net
+        self.f_net = f_net
+        for net in (self.d_net, self.f_net):
+            for prm in net.parameters():
+                prm.requires_grad = False
+            net.eval()
+
+        self.sampling_range = args.MAGNET_sampling_range
+        self.n_samples = args.MAGNET_num_samples
+        self.weighting = args.MAGNET_mvs_weighting
+        self.train_iter = args.MAGNET_num_train_iter
+        self.test_iter = args.MAGNET_num_test_iter
+        self.dpv_height = args.dpv_height
+        self.dpv_width = args.dpv_width
+        self.k_list = self.depth_sampling()
+        self.downsample_ratio = args.downsample_ratio
+        self.feat_dtype = feat_dtype
+        self.matcher_path = 0          # 0 auto / 1 generic / 2 window kernel (include/magnet_hip.h `path`)
+
+        dnet_fdim = 256
+        self.g_net = GNET(ch_in=dnet_fdim + self.n_samples, ch_out=2)
+        h_dim = 128
+        self.mask_head = nn.Sequential(
+            nn.Conv2d(dnet_fdim, h_dim, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(h_dim, h_dim, 1), nn.ReLU(inplace=True),
+            nn.Conv2d(h_dim, h_dim, 1), nn.ReLU(inplace=True),
+            nn.Conv2d(h_dim, 9 * self.downsample_ratio * self.downsample_ratio, 1))
+        self.upsample_depth = upsample_depth_via_mask
+
+    def depth_sampling(self):
+        return depth_sampling(self.sampling_range, self.n_samples)
+
+    # -- the hot path proper: everything after the backbones --------------------------------------
+    def match_and_refine(self, ref_gmms, x_d3, ref_feat_4, nghbr_feat_4, nghbr_gmms, nghbr_poses,
+                         is_valid, cam_intrins, mode="test"):
+        """MAGNET.py:146-175 from backbone outputs.  Returns the list of upsampled (B,2,H,W)."""
+        thres = int(self.weighting.split("CW")[1])
+        matcher = CostVolumeCW(ref_feat_4, nghbr_feat_4, nghbr_gmms, nghbr_poses, is_valid, cam_intrins,
+                               thres, feat_dtype=self.feat_dtype, path=self.matcher_path)
+        B, _, h, w = ref_gmms.shape
+        n_iter = self.train_iter if mode == "train" else self.test_iter
+        # G-Net input buffer: cost volume first, then x_d3 (MAGNET.py:167); x_d3 is copied once
+        gnet_in = torch.empty((B, self.n_samples + x_d3.shape[1], h, w), dtype=torch.float32, device=x_d3.device)
+        gnet_in[:, self.n_samples:] = x_d3
+        cost_view = gnet_in[:, :self.n_samples]          # the kernel writes here directly (strided frames)
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.g_net.parameters())
+        pred_list = [ref_gmms]
+        for _ in range(n_iter):
+            matcher(ref_gmm=pred_list[-1].detach(), k_list=self.k_list, out=cost_view)  # MAGNET.py:153-164
+            # autograd saves G-Net's input, so training gets a fresh tensor per iteration (as the
+            # reference's torch.cat does, MAGNET.py:167); inference reuses the buffer in place.
+            g_in = gnet_in.clone() if training else gnet_in
+            new_pred = self.g_net(g_in, pred_list[-1].detach())                         # MAGNET.py:167-168
+            pred_list.append(new_pred)
+        mask = self.mask_head(x_d3)                                                       # MAGNET.py:172
+        return [self.upsample_depth(pred, mask, self.downsample_ratio) for pred in pred_list[1:]]
+
+    def forward(self, ref_img, nghbr_imgs, nghbr_poses, is_valid, cam_intrins, mode="train"):
+        B = ref_img.shape[0]
+        with torch.no_grad():
+            mono_gmms, x_d3 = self.d_net(torch.cat((ref_img, nghbr_imgs), dim=0))        # MAGNET.py:135
+            mono_gmms = mono_gmms.detach()
+            ref_gmms = mono_gmms[:B, ...]
+            x_d3 = x_d3[:B, ...]
+            nghbr_gmms = mono_gmms[B:, ...]
+            feat_4 = self.f_net(torch.cat((ref_img, nghbr_imgs), dim=0))                 # MAGNET.py:142
+            ref_feat_4 = feat_4[:B, ...]
+            nghbr_feat_4 = feat_4[B:, ...]
+        return self.match_and_refine(ref_gmms, x_d3, ref_feat_4, nghbr_feat_4, nghbr_gmms, nghbr_poses,
+                                     is_valid, cam_intrins, mode)

@@ -1,0 +1,35 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    """Golden vectors captured from the imported reference (tests/golden/make_golden.py)."""
+    return np.load(os.path.join(REPO, "tests", "golden", "golden_v1.npz"))
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """Build (if stale) and load libmagnet_hip.so."""
+    from magnet_amd import build, lib
+    build.build()
+    return lib.load()
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("test marked gpu but no GPU is visible — the HIP path must run, there is no CPU fallback")
+    return torch.device("cuda:0")

@@ -1,0 +1,52 @@
+"""Shared parity helpers for the GPU tests: how a HIP cost volume is compared with the oracle.
+
+The consistency gate |z - mu_w| < kappa*sigma_w (reference homography.py:157-158) is a hard
+threshold, so a 1-ulp difference in any upstream quantity can flip a gate and change one cost
+entry by a full feature dot product.  Parity is therefore judged as:
+  (a) the fraction of entries that differ by more than rounding ("flip candidates") is <= flip_frac,
+  (b) everywhere else |hip - oracle| <= atol + rtol*|oracle|,
+  (c) downstream, the final-depth abs_rel delta stays < 1e-4 (tests that run the full loop).
+"""
+import numpy as np
+import torch
+
+from oracle import oracle
+
+
+def to_dev(inp, device):
+    out = {}
+    for k, v in inp.items():
+        if k == "cam_intrins":
+            out[k] = v                      # stays on the CPU like the reference's loader hands it over
+        elif k == "is_valid":
+            out[k] = v
+        else:
+            out[k] = v.to(device)
+    return out
+
+
+def oracle_cost(inp, k_list, kappa=5.0, d_volume=None, aux=False):
+    return oracle.cost_volume_cw(d_volume, inp["ref_gmms"], k_list, inp["ref_feat"], inp["nghbr_feat"],
+                                 inp["nghbr_gmms"], inp["nghbr_poses"], inp["is_valid"],
+                                 inp["cam_intrins"]["intM"], inp["cam_intrins"]["unit_ray_array_2D"],
+                                 kappa, return_aux=aux)
+
+
+def cost_stats(hip, orc, atol=2e-5, rtol=2e-5):
+    hip = hip.detach().cpu().numpy() if isinstance(hip, torch.Tensor) else np.asarray(hip)
+    diff = np.abs(hip.astype(np.float64) - orc.astype(np.float64))
+    bad = diff > (atol + rtol * np.abs(orc))
+    good = ~bad
+    return dict(frac_bitwise=float(np.mean(hip == orc)), frac_flip=float(bad.mean()),
+                max_abs_nonflip=float(diff[good].max()) if good.any() else 0.0,
+                max_abs=float(diff.max()), n=int(diff.size), finite=bool(np.isfinite(hip).all()))
+
+
+def assert_cost_parity(hip, orc, flip_frac=1e-5, atol=2e-5, rtol=2e-5, bitwise_frac=None, label=""):
+    st = cost_stats(hip, orc, atol, rtol)
+    print(f"[parity {label}] {st}")
+    assert st["finite"], f"{label}: non-finite values in the HIP cost volume"
+    assert st["frac_flip"] <= flip_frac, f"{label}: {st}"
+    if bitwise_frac is not None:
+        assert st["frac_bitwise"] >= bitwise_frac, f"{label}: {st}"
+    return st

@@ -1,0 +1,245 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from magnet_amd import synth
+from oracle import oracle
+from tests.parity import assert_cost_parity, oracle_cost, to_dev
+from tests.stubs import StubDNet, StubFNet, make_args, seeded_magnet_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip_cost(inp, k_list, device, feat_dtype="fp32", d_volume=None, path=0, kappa=5, out=None):
+    from magnet_amd.homography import CostVolumeCW
+    d = to_dev(inp, device)
+    cv = CostVolumeCW(d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"],
+                      d["cam_intrins"], kappa, feat_dtype=feat_dtype, path=path)
+    if d_volume is not None:
+        return cv(d_volume=d_volume.to(device), out=out)
+    return cv(ref_gmm=d["ref_gmms"], k_list=k_list, out=out)
+
+
+def _golden_tiny(g):
+    return dict(ref_feat=torch.from_numpy(g["G2_ref_feat"]), nghbr_feat=torch.from_numpy(g["G2_nghbr_feat"]),
+                ref_gmms=torch.from_numpy(g["G2_ref_gmms"]), nghbr_gmms=torch.from_numpy(g["G2_nghbr_gmms"]),
+                nghbr_poses=torch.from_numpy(g["G2_nghbr_poses"]), is_valid=torch.from_numpy(g["G2_is_valid"]),
+                cam_intrins={"intM": torch.from_numpy(g["G2_intM"]), "unit_ray_array_2D": torch.from_numpy(g["G2_rays"])})
+
+
+def test_device_is_gfx950(hip_lib, gpu):
+    assert hip_lib.magnet_device_count() >= 1
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+# ---- pack ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(3, 8, 5, 7), (2, 64, 12, 16), (1, 64, 120, 160), (2, 72, 9, 33)])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_pack_features(hip_lib, gpu, shape, dtype):
+    from magnet_amd import lib
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
+    got = lib.pack_features(x.to(gpu), lib.feat_enum(dtype)).cpu()
+    exp = x.permute(0, 2, 3, 1).contiguous()
+    if dtype == "bf16":
+        exp = exp.to(torch.bfloat16)
+    assert got.dtype == exp.dtype and torch.equal(got, exp)        # bit-exact (RNE for bf16)
+
+
+# ---- cost volume: golden (reference) vectors -------------------------------------------------------
+@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("fused", [True, False])
+def test_cost_volume_tiny_golden(hip_lib, gpu, golden, path, fused):
+    """The reference's own output on the edge-case vector (invalid view, behind-camera pose, OOB)."""
+    inp = _golden_tiny(golden)
+    k = list(golden["G1_k_D5"])
+    dv = None if fused else torch.from_numpy(golden["G2_d_volume"])
+    got = _hip_cost(inp, k, gpu, d_volume=dv, path=path)
+    assert_cost_parity(got, golden["G2_cost"], flip_frac=0.0, label=f"tiny path={path} fused={fused}")
+
+
+def test_cost_volume_reference_signature(hip_lib, gpu, golden):
+    """homography.est_costvolume_CW(d_volume, ref_feat, nghbr_feat, ref_gmms, nghbr_gmms, R, t,
+    is_valid, cam_intrins, thres) with is_valid / cam_intrins on the CPU, as test_MaGNet.py passes them."""
+    from magnet_amd import homography
+    inp = _golden_tiny(golden)
+    d = to_dev(inp, gpu)
+    R = d["nghbr_poses"][:, :, :3, :3]; t = d["nghbr_poses"][:, :, :3, 3]
+    got = homography.est_costvolume_CW(torch.from_numpy(golden["G2_d_volume"]).to(gpu), d["ref_feat"],
+                                       d["nghbr_feat"], d["ref_gmms"], d["nghbr_gmms"], R, t,
+                                       inp["is_valid"], inp["cam_intrins"], 5)
+    assert got.shape == (2, 5, 12, 16) and got.dtype == torch.float32 and got.device.type == "cuda"
+    assert_cost_parity(got, golden["G2_cost"], flip_frac=0.0, label="reference signature")
+
+
+def test_cost_volume_C1_golden_subsample(hip_lib, gpu, golden):
+    wl = synth.WORKLOADS["C1"]
+    inp = synth.make_inputs(wl, B=1, seed=0)
+    got = _hip_cost(inp, list(golden["G1_k_D16"]), gpu).cpu().numpy()
+    assert_cost_parity(got[:, :, ::5, ::7], golden["G2_C1_cost_sub"], flip_frac=2e-5, label="C1 golden")
+
+
+# ---- cost volume: oracle on seeded inputs ------------------------------------------------------------
+CASES = [
+    # name, workload, B, seed, feat_dtype, invalid
+    ("C1", "C1", 1, 0, "fp32", ()),
+    ("C1-b2-invalid", "C1", 2, 1, "fp32", ((0, 1),)),
+    ("C2-fp32", "C2", 1, 0, "fp32", ()),
+    ("C2-bf16", "C2", 2, 1, "bf16", ((1, 2),)),
+    ("C5", "C5", 1, 2, "fp32", ()),
+    ("shipped-D5", "shipped", 2, 0, "fp32", ()),
+]
+
+
+@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("name,wlname,B,seed,fdt,invalid", CASES)
+def test_cost_volume_vs_oracle(hip_lib, gpu, name, wlname, B, seed, fdt, invalid, path):
+    wl = synth.WORKLOADS[wlname]
+    inp = synth.make_inputs(wl, B=B, seed=seed, invalid=list(invalid), round_bf16=(fdt == "bf16"))
+    k = oracle.depth_sampling(3, wl.D)
+    orc = oracle_cost(inp, k)
+    got = _hip_cost(inp, k, gpu, feat_dtype=fdt, path=path)
+    assert_cost_parity(got, orc, flip_frac=2e-5, label=f"{name} path={path}")
+
+
+def test_cost_volume_kitti_wide_aspect(hip_lib, gpu):
+    """C4: 88x304, V=4, D=128, KITTI forward motion (long epipolar segments, many OOB samples)."""
+    wl = synth.WORKLOADS["C4"]
+    inp = synth.make_inputs(wl, B=1, seed=0)
+    k = oracle.depth_sampling(3, wl.D)
+    orc = oracle_cost(inp, k)
+    got = _hip_cost(inp, k, gpu)
+    assert_cost_parity(got, orc, flip_frac=5e-5, label="C4 kitti")
+
+
+def test_cost_volume_ragged_grid_and_odd_D(hip_lib, gpu):
+    """Grid not a multiple of the 16x4 tile, D not a multiple of 4, F=8, V=1."""
+    wl = synth.Workload("ragged", "scannet", 13, 19, V=1, D=7, F=8)
+    inp = synth.make_inputs(wl, B=3, seed=4)
+    k = oracle.depth_sampling(3, wl.D)
+    orc = oracle_cost(inp, k)
+    for path in (0, 1):
+        got = _hip_cost(inp, k, gpu, path=path)
+        assert_cost_parity(got, orc, flip_frac=0.0, label=f"ragged path={path}")
+
+
+def test_cost_volume_all_views_invalid_is_zero(hip_lib, gpu):
+    wl = synth.Workload("inv", "scannet", 12, 16, V=2, D=5, F=8)
+    inp = synth.make_inputs(wl, B=1, seed=5, invalid=[(0, 0), (0, 1)])
+    got = _hip_cost(inp, oracle.depth_sampling(3, 5), gpu)
+    assert torch.count_nonzero(got) == 0
+
+
+def test_cost_volume_strided_output_into_gnet_buffer(hip_lib, gpu):
+    """The kernel writes the first D channels of G-Net's (B, D+256, h, w) input directly."""
+    wl = synth.Workload("s", "scannet", 12, 16, V=2, D=5, F=8)
+    inp = synth.make_inputs(wl, B=2, seed=6)
+    k = oracle.depth_sampling(3, 5)
+    buf = torch.full((2, 5 + 3, 12, 16), 7.0, device=gpu)
+    _hip_cost(inp, k, gpu, out=buf[:, :5])
+    dense = _hip_cost(inp, k, gpu)
+    assert torch.equal(buf[:, :5], dense) and torch.all(buf[:, 5:] == 7.0)
+
+
+def test_linearity_in_reference_features(hip_lib, gpu):
+    """Size-independent property at the full C2 shape: the score is linear in the reference
+    features for fixed gates (scaling ref features by 2 scales the cost volume by exactly 2)."""
+    wl = synth.WORKLOADS["C2"]
+    inp = synth.make_inputs(wl, B=1, seed=3)
+    k = oracle.depth_sampling(3, wl.D)
+    a = _hip_cost(inp, k, gpu, feat_dtype="bf16")
+    inp2 = dict(inp); inp2["ref_feat"] = inp["ref_feat"] * 2.0
+    b = _hip_cost(inp2, k, gpu, feat_dtype="bf16")
+    assert torch.equal(b, a * 2.0)
+
+
+# ---- gaussian update / upsample ------------------------------------------------------------------------
+def test_gaussian_update_golden(hip_lib, gpu, golden):
+    from magnet_amd import lib
+    got = lib.gaussian_update(torch.from_numpy(golden["G4_raw"]).to(gpu), torch.from_numpy(golden["G4_prev"]).to(gpu))
+    np.testing.assert_allclose(got.cpu().numpy(), golden["G4_out"], rtol=0, atol=1e-6)
+    x = torch.randn(3, 2, 37, 53, generator=torch.Generator().manual_seed(2)) * 3
+    g = torch.rand(3, 2, 37, 53, generator=torch.Generator().manual_seed(3)) + 0.1
+    got = lib.gaussian_update(x.to(gpu), g.to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.gaussian_update(x.numpy(), g.numpy()), rtol=1e-6, atol=1e-6)
+
+
+def test_gnet_forward_golden(hip_lib, gpu, golden):
+    """GNET.forward (conv stack on MIOpen + HIP tail) against the reference's output, with the
+    reference's seeded weights reconstructed from the same generator."""
+    from magnet_amd.magnet import GNET
+    torch.manual_seed(11)
+    net = GNET(ch_in=261)                     # same construction order as the golden generator
+    assert torch.equal(net.state_dict()["gnet.6.bias"], torch.from_numpy(golden["G4_sd_gnet.6.bias"]))
+    net = net.to(gpu).eval()
+    with torch.no_grad():
+        y = net(torch.from_numpy(golden["G4_x"]).to(gpu), torch.from_numpy(golden["G4_prev"]).to(gpu))
+    np.testing.assert_allclose(y.cpu().numpy(), golden["G4_out"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k", [4, 2])
+def test_upsample(hip_lib, gpu, golden, k):
+    from magnet_amd import lib
+    if k == 4:
+        got = lib.upsample_depth(torch.from_numpy(golden["G5_depth"]).to(gpu), torch.from_numpy(golden["G5_mask"]).to(gpu), 4)
+        np.testing.assert_allclose(got.cpu().numpy(), golden["G5_out"], rtol=0, atol=3e-6)
+    g = torch.Generator().manual_seed(9)
+    d = torch.rand(2, 2, 11, 70, generator=g) * 4; m = torch.randn(2, 9 * k * k, 11, 70, generator=g) * 2
+    got = lib.upsample_depth(d.to(gpu), m.to(gpu), k).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.upsample_depth_via_mask(d.numpy(), m.numpy(), k), rtol=0, atol=5e-6)
+
+
+# ---- full loop ----------------------------------------------------------------------------------------------
+def test_magnet_forward_matches_reference_output(hip_lib, gpu, golden):
+    """G6: the reference's MAGNET.forward output (stub D-Net/F-Net, I=3, one invalid view) vs ours:
+    final-depth abs_rel delta < 1e-4 (BASELINE.json's parity bar)."""
+    from magnet_amd.magnet import MAGNET
+    args = make_args(D=5, iters=3, dpv_h=12, dpv_w=16)
+    m = MAGNET(args, d_net=StubDNet(seed=21), f_net=StubFNet(seed=22, fdim=8))
+    seeded_magnet_weights(m, seed=23)
+    m = m.to(gpu).eval()
+    intr = synth.make_intrinsics("scannet", 12, 16, 2)
+    with torch.no_grad():
+        preds = m(torch.from_numpy(golden["G6_ref_img"]).to(gpu), torch.from_numpy(golden["G6_nghbr_imgs"]).to(gpu),
+                  torch.from_numpy(golden["G6_poses"]).to(gpu), torch.from_numpy(golden["G6_is_valid"]), intr, mode="test")
+    assert len(preds) == 3
+    for i, p in enumerate(preds):
+        ref = golden[f"G6_pred{i}"]
+        assert tuple(p.shape) == ref.shape == (2, 2, 48, 64)
+        got = p.cpu().numpy()
+        ar = oracle.abs_rel(ref[:, 0], got[:, 0])
+        print(f"[G6 iter {i}] abs_rel(ours vs reference mu) = {ar:.3e}; max|dmu|={np.abs(got[:,0]-ref[:,0]).max():.3e}")
+        assert ar < 1e-4
+        np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=5e-3, atol=1e-6)
+
+
+def test_full_loop_abs_rel_C3_shape(hip_lib, gpu):
+    """C3 shape (120x160, V=4, D=64, I=3, bf16 storage): HIP loop vs an oracle loop (oracle matcher +
+    torch-CPU G-Net + oracle tail/upsample) on identical inputs: abs_rel delta < 1e-4."""
+    from magnet_amd.magnet import MAGNET
+    wl = synth.WORKLOADS["C3"]
+    inp = synth.make_inputs(wl, B=1, seed=0)
+    args = make_args(D=wl.D, iters=3, dpv_h=wl.h, dpv_w=wl.w)
+    m = MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2), feat_dtype="bf16")
+    seeded_magnet_weights(m, seed=5)
+    x_d3 = torch.randn(1, 256, wl.h, wl.w, generator=torch.Generator().manual_seed(7)) * 0.5
+    # oracle loop on the CPU
+    k = oracle.depth_sampling(3, wl.D)
+    gmm = inp["ref_gmms"].clone(); cpu_preds = []
+    with torch.no_grad():
+        mask = m.mask_head(x_d3)
+        for _ in range(3):
+            cost = torch.from_numpy(oracle_cost(dict(inp, ref_gmms=gmm), k))
+            raw = m.g_net.gnet(torch.cat([cost, x_d3], dim=1))
+            gmm = torch.from_numpy(oracle.gaussian_update(raw.numpy(), gmm.numpy()))
+            cpu_preds.append(oracle.upsample_depth_via_mask(gmm.numpy(), mask.numpy(), 4))
+    m = m.to(gpu).eval()
+    d = to_dev(inp, gpu)
+    with torch.no_grad():
+        preds = m.match_and_refine(d["ref_gmms"], x_d3.to(gpu), d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"],
+                                   d["nghbr_poses"], inp["is_valid"], inp["cam_intrins"], mode="test")
+    for i, (p, c) in enumerate(zip(preds, cpu_preds)):
+        got = p.cpu().numpy()
+        ar = oracle.abs_rel(np.abs(c[:, 0]) + 1e-3, np.abs(got[:, 0]) + 1e-3)
+        print(f"[C3 loop iter {i}] abs_rel delta = {ar:.3e}")
+        assert np.isfinite(got).all() and ar < 1e-4

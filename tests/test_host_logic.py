@@ -1,0 +1,64 @@
+"""Host-side logic that needs no GPU: sampling offsets, synthetic generator contracts, the MAGNET
+module's interface (constructor fields, state_dict keys), the sharding helper."""
+import numpy as np
+import pytest
+import torch
+
+from magnet_amd import synth
+from magnet_amd.magnet import MAGNET, GNET, depth_sampling
+from tests.stubs import StubDNet, StubFNet, make_args, seeded_magnet_weights
+
+
+@pytest.mark.parametrize("D", [5, 16, 64, 128])
+def test_depth_sampling_matches_reference(golden, D):
+    np.testing.assert_allclose(depth_sampling(3, D), golden[f"G1_k_D{D}"], rtol=0, atol=2e-15)
+
+
+def test_workload_bytes_match_survey_table():
+    # SURVEY.md §8(d) / BASELINE.md §3 table (MB, decimal)
+    exp = {"C1": 17.5, "C2": 18.0, "C4": 49.0, "C5": 40.4, "C2L": 288, "C2Lf": 484, "C4L": 784}
+    for k, v in exp.items():
+        got = synth.WORKLOADS[k].algorithmic_bytes() / 1e6
+        assert abs(got - v) / v < 0.01, (k, got, v)
+
+
+def test_synth_layouts():
+    wl = synth.WORKLOADS["C1"]
+    inp = synth.make_inputs(wl, B=2, seed=1, invalid=[(0, 1)])
+    assert inp["nghbr_feat"].shape == (wl.V * 2, wl.F, wl.h, wl.w)
+    assert inp["nghbr_poses"].shape == (2, wl.V, 4, 4) and inp["is_valid"].dtype == torch.int32
+    assert inp["is_valid"][0, 1] == 0 and inp["is_valid"].sum() == 2 * wl.V - 1
+    rays = inp["cam_intrins"]["unit_ray_array_2D"]
+    assert rays.shape == (2, 3, wl.hw) and torch.all(rays[:, 2] == 1)
+    # rotation blocks are orthonormal
+    R = inp["nghbr_poses"][:, :, :3, :3].double()
+    assert torch.allclose(R @ R.transpose(-1, -2), torch.eye(3, dtype=torch.float64).expand_as(R), atol=1e-6)
+    # bf16 workloads hand the oracle bf16-representable features
+    inp2 = synth.make_inputs(synth.WORKLOADS["C2"], B=1, seed=0)
+    f = inp2["ref_feat"]
+    assert torch.equal(f, f.to(torch.bfloat16).float())
+
+
+def test_magnet_module_interface():
+    args = make_args(D=5, iters=3, dpv_h=12, dpv_w=16)
+    m = MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2, fdim=8))
+    keys = set(m.state_dict().keys())
+    # the reference's checkpoint key names (models/MAGNET.py:108-118)
+    for i in (0, 2, 4, 6):
+        assert f"g_net.gnet.{i}.weight" in keys and f"mask_head.{i}.weight" in keys
+    assert m.g_net.gnet[0].in_channels == 256 + 5 and m.mask_head[6].out_channels == 9 * 16
+    assert len(m.k_list) == 5 and not any(p.requires_grad for p in m.d_net.parameters())
+    n = sum(p.numel() for p in m.g_net.parameters())
+    assert n == 334082                                  # SURVEY.md §8a A6, D=5
+    seeded_magnet_weights(m, 3)
+    assert isinstance(m.g_net, GNET)
+
+
+def test_magnet_forward_refuses_cpu():
+    from magnet_amd import lib
+    args = make_args(D=5, iters=1, dpv_h=12, dpv_w=16)
+    m = MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2, fdim=8))
+    img = torch.rand(1, 3, 48, 64)
+    with pytest.raises(lib.MagnetError):
+        m(img, torch.rand(2, 3, 48, 64), synth.make_poses("scannet", 1, 2, torch.Generator().manual_seed(0)),
+          torch.ones(1, 2, dtype=torch.int32), synth.make_intrinsics("scannet", 12, 16, 1), mode="test")
