@@ -5,6 +5,7 @@
  *
  *   magnet_pack_features     -> the layout hand-off from F-Net's NCHW fp32 output
  *                               (models/MAGNET.py:142-144) to the kernel's channel-last storage
+ *   magnet_pack_gmm          -> the same for D-Net's source-view (mu,sigma) maps (models/MAGNET.py:139)
  *   magnet_cost_volume_cw    -> homography.est_costvolume_CW  (models/submodules/homography.py:79-121)
  *                               + _compute_cost_CW            (homography.py:124-161)
  *                               + the candidate sampling in front of it (models/MAGNET.py:153-156)
@@ -55,9 +56,12 @@ typedef struct MagnetCostVolumeArgs {
     int32_t B, V, F, D, h, w;              /* ref frames, source views, channels (F % 8 == 0), candidates, grid */
     float   kappa;                         /* consistency threshold: int(weighting.split('CW')[1]), MAGNET.py:159 */
     int32_t feat_dtype;                    /* MAGNET_FEAT_* of ref_feat_cl / src_feat_cl */
-    const void    *ref_feat_cl;            /* (B,   h, w, F) channel-last  (from magnet_pack_features) */
-    const void    *src_feat_cl;            /* (V*B, h, w, F) channel-last, view-major */
-    const float   *src_gmm;                /* (V*B, 2, h, w) source-view [mu, sigma] */
+    const void    *ref_feat_cl;            /* (B, h, w, F) channel-last            (magnet_pack_features, pad = 0) */
+    const void    *src_feat_pad;           /* (V*B, h+2, w+2, F) channel-last with a one-texel ZERO border, view-major
+                                              (magnet_pack_features, pad = 1): grid_sample's zeros padding
+                                              (homography.py:150) becomes plain loads */
+    const float   *src_gmm_pad;            /* (V*B, h+2, w+2, 2) interleaved source [mu, sigma], zero border
+                                              (magnet_pack_gmm) */
     const float   *ref_gmm;                /* (B, 2, h, w) reference [mu, sigma]; used when d_volume == NULL */
     const double  *k_list;                 /* HOST, D float64 quantile offsets (MAGNET.depth_sampling, MAGNET.py:120-128);
                                               used when d_volume == NULL: d_j = mu + sigma*(float)k_j */
@@ -68,10 +72,10 @@ typedef struct MagnetCostVolumeArgs {
     const float   *intM;                   /* (B,3,3) intrinsics at grid resolution */
     const float   *rays;                   /* (B,3,h*w) unit_ray_array_2D */
     float         *cost;                   /* OUT (B,D,h,w) fp32; frame b starts at cost + b*cost_batch_stride */
-    int32_t        path;                   /* 0 = auto; 1 = force the generic gather path; 2 = force the
-                                              LDS-window/MFMA path (tiles that do not fit still fall back) */
-    uint32_t      *stats;                  /* optional device uint32[4]: {tiles on the window path, tiles on the
-                                              generic path, 0, 0}, accumulated with atomics; NULL = off */
+    int32_t        path;                   /* 0 = auto (worklist kernel when the shape allows); 1 = force the generic
+                                              (bit-exact) gather kernel; 2 = require the worklist kernel */
+    uint32_t      *stats;                  /* optional device uint32[4]: {tiles run by the worklist kernel, tiles run by
+                                              the generic kernel, 0, 0}, accumulated with atomics; NULL = off */
     int64_t        cost_batch_stride;      /* elements between consecutive frames of `cost`; 0 = D*h*w (dense).
                                               Lets the kernel write the first D channels of G-Net's
                                               (B, D+256, h, w) input directly (models/MAGNET.py:167). */
@@ -83,9 +87,13 @@ MAGNET_API const char *magnet_last_error(void);
 /* Number of gfx950 devices visible to the HIP runtime this library is bound to (0 if none). */
 MAGNET_API int magnet_device_count(void);
 
-/* NCHW fp32 (N,F,h,w) -> channel-last (N,h,w,F) in `out_dtype` (round-to-nearest-even for bf16). */
+/* NCHW fp32 (N,F,h,w) -> channel-last (N,h+2*pad,w+2*pad,F) in `out_dtype` (round-to-nearest-even for
+ * bf16); pad = 1 surrounds every image with one texel of zeros. */
 MAGNET_API int magnet_pack_features(const float *nchw, void *out_cl, int32_t N, int32_t F, int32_t h, int32_t w,
-                         int32_t out_dtype, void *stream);
+                         int32_t out_dtype, int32_t pad, void *stream);
+
+/* (N,2,h,w) fp32 [mu,sigma] planes -> (N,h+2,w+2,2) interleaved with a one-texel zero border. */
+MAGNET_API int magnet_pack_gmm(const float *gmm_nchw, float *out_pad, int32_t N, int32_t h, int32_t w, void *stream);
 
 /* Consistency-weighted multi-view matching score, all (b, pixel, candidate) in one launch. */
 MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs *args, void *stream);

@@ -7,7 +7,8 @@
 #include "cv_common.hpp"
 
 namespace magnet {
-hipError_t launch_pack(const float*, void*, int, int, int, int, bool, hipStream_t);
+hipError_t launch_pack(const float*, void*, int, int, int, int, bool, int, hipStream_t);
+hipError_t launch_pack_gmm(const float*, float*, int, int, int, hipStream_t);
 hipError_t launch_gaussian_update(const float*, const float*, float*, int, int, hipStream_t);
 hipError_t launch_upsample(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 }
@@ -46,20 +47,28 @@ MAGNET_API int magnet_device_count(void) {
 }
 
 MAGNET_API int magnet_pack_features(const float* nchw, void* out_cl, int32_t N, int32_t F, int32_t h, int32_t w,
-                         int32_t out_dtype, void* stream) {
+                         int32_t out_dtype, int32_t pad, void* stream) {
     if (!nchw || !out_cl) return fail(MAGNET_E_NULL, "magnet_pack_features: NULL pointer");
     if (N <= 0 || F <= 0 || h <= 0 || w <= 0 || (F % 8) != 0)
         return fail(MAGNET_E_DIM, "magnet_pack_features: bad dims N=%d F=%d h=%d w=%d (F must be a multiple of 8)", N, F, h, w);
     if (out_dtype != MAGNET_FEAT_F32 && out_dtype != MAGNET_FEAT_BF16)
         return fail(MAGNET_E_DTYPE, "magnet_pack_features: unknown dtype %d", out_dtype);
+    if (pad != 0 && pad != 1) return fail(MAGNET_E_DIM, "magnet_pack_features: pad must be 0 or 1");
     if (!aligned16(out_cl)) return fail(MAGNET_E_ALIGN, "magnet_pack_features: out_cl not 16-byte aligned");
-    hipError_t e = magnet::launch_pack(nchw, out_cl, N, F, h, w, out_dtype == MAGNET_FEAT_BF16, (hipStream_t)stream);
+    hipError_t e = magnet::launch_pack(nchw, out_cl, N, F, h, w, out_dtype == MAGNET_FEAT_BF16, pad, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_pack_features launch");
+}
+
+MAGNET_API int magnet_pack_gmm(const float* gmm_nchw, float* out_pad, int32_t N, int32_t h, int32_t w, void* stream) {
+    if (!gmm_nchw || !out_pad) return fail(MAGNET_E_NULL, "magnet_pack_gmm: NULL pointer");
+    if (N <= 0 || h <= 0 || w <= 0) return fail(MAGNET_E_DIM, "magnet_pack_gmm: bad dims N=%d h=%d w=%d", N, h, w);
+    hipError_t e = magnet::launch_pack_gmm(gmm_nchw, out_pad, N, h, w, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_pack_gmm launch");
 }
 
 MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream) {
     if (!a) return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: args is NULL");
-    if (!a->ref_feat_cl || !a->src_feat_cl || !a->src_gmm || !a->poses || !a->is_valid || !a->intM ||
+    if (!a->ref_feat_cl || !a->src_feat_pad || !a->src_gmm_pad || !a->poses || !a->is_valid || !a->intM ||
         !a->rays || !a->cost)
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: a required pointer is NULL");
     if (!a->d_volume && (!a->ref_gmm || !a->k_list))
@@ -71,7 +80,7 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
     if ((a->F % 8) != 0) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: F=%d must be a multiple of 8", a->F);
     if (a->feat_dtype != MAGNET_FEAT_F32 && a->feat_dtype != MAGNET_FEAT_BF16)
         return fail(MAGNET_E_DTYPE, "magnet_cost_volume_cw: unknown feat_dtype %d", a->feat_dtype);
-    if (!aligned16(a->ref_feat_cl) || !aligned16(a->src_feat_cl))
+    if (!aligned16(a->ref_feat_cl) || !aligned16(a->src_feat_pad))
         return fail(MAGNET_E_ALIGN, "magnet_cost_volume_cw: feature pointers must be 16-byte aligned");
     if ((size_t)a->h * a->w * (size_t)a->F * (size_t)a->V * (size_t)a->B >= ((size_t)1 << 40))
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: problem too large");
@@ -85,7 +94,7 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: grid too large");
     p.feat_bf16 = (a->feat_dtype == MAGNET_FEAT_BF16);
     p.kappa = a->kappa;
-    p.ref_feat = a->ref_feat_cl; p.src_feat = a->src_feat_cl; p.src_gmm = a->src_gmm;
+    p.ref_feat = a->ref_feat_cl; p.src_feat = a->src_feat_pad; p.src_gmm = a->src_gmm_pad;
     p.ref_gmm = a->ref_gmm; p.d_volume = a->d_volume; p.poses = a->poses; p.is_valid = a->is_valid;
     p.intM = a->intM; p.rays = a->rays; p.cost = a->cost; p.stats = a->stats;
     p.cost_bstride = a->cost_batch_stride ? a->cost_batch_stride : (long long)a->D * a->h * a->w;
@@ -97,11 +106,11 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
     hipError_t e = hipSuccess;
     bool handled = false;
     if (a->path != 1) {
-        e = magnet::launch_cv_window(p, (hipStream_t)stream, &handled);
-        if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw window launch");
+        e = magnet::launch_cv_worklist(p, (hipStream_t)stream, &handled);
+        if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw worklist launch");
     }
     if (!handled) {
-        if (a->path == 2) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: window path does not support this shape/dtype");
+        if (a->path == 2) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the worklist kernel does not take this shape (D > 128 or very wide F)");
         e = magnet::launch_cv_generic(p, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw generic launch");
     }

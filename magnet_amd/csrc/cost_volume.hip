@@ -9,8 +9,8 @@
 //   cv_generic_kernel : for each (pixel, candidate, view) gathers the 4 bilinear taps x F channels
 //                       straight from the channel-last feature maps (L1/L2 served).  Arithmetic is
 //                       the oracle's to the bit (per-channel fused bilerp, ATen cascade sum).  It is
-//                       the fallback for tiles whose source footprint does not fit the LDS window.
-//   (window/MFMA kernel: see cost_volume_window.hip)
+//                       the bit-exact reference path and the fallback for shapes the worklist kernel does not take.
+//   cv_worklist_kernel: the fast path, see cost_volume_worklist.hip
 #include "cv_common.hpp"
 
 namespace magnet {
@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void cv_generic_kernel(const CvParams p) {
         sg = p.ref_gmm[((size_t)b * 2 + 1) * hw + pix];
     }
     const GridConst gc = grid_const(p);
+    const int Wp = p.w + 2, Hp = p.h + 2;
     const FeatT* __restrict__ ref = reinterpret_cast<const FeatT*>(p.ref_feat) + ((size_t)b * hw + pix) * p.F;
 
     const float fV = (float)p.V;
@@ -86,31 +87,27 @@ __global__ __launch_bounds__(256) void cv_generic_kernel(const CvParams p) {
             const PixelView pv = make_pixel_view(p.intM + (size_t)b * 9,
                                                  p.poses + ((size_t)b * p.V + v) * 16, r0, r1, r2);
             const size_t sidx = (size_t)v * p.B + b;               // view-major, homography.py:105
-            const FeatT* __restrict__ src = reinterpret_cast<const FeatT*>(p.src_feat) + sidx * hw * p.F;
-            const float* __restrict__ smu = p.src_gmm + (sidx * 2 + 0) * hw;
-            const float* __restrict__ ssg = p.src_gmm + (sidx * 2 + 1) * hw;
+            const FeatT* __restrict__ src = reinterpret_cast<const FeatT*>(p.src_feat) + sidx * (size_t)Hp * Wp * p.F;
+            const float* __restrict__ sgm = p.src_gmm + sidx * (size_t)Hp * Wp * 2;
             float ix, iy, zw;
             project(pv, gc, d, ix, iy, zw);
             const Taps t = make_taps(ix, iy);
-            const bool xa = (t.x0 >= 0) && (t.x0 < p.w), xb = (t.x0 + 1 >= 0) && (t.x0 + 1 < p.w);
-            const bool ya = (t.y0 >= 0) && (t.y0 < p.h), yb = (t.y0 + 1 >= 0) && (t.y0 + 1 < p.h);
-            const bool in_nw = xa && ya, in_ne = xb && ya, in_sw = xa && yb, in_se = xb && yb;
-            // clamp tap addresses (weights of out-of-image taps are applied to zeros)
-            const int x0c = min(max(t.x0, 0), p.w - 1), x1c = min(max(t.x0 + 1, 0), p.w - 1);
-            const int y0c = min(max(t.y0, 0), p.h - 1), y1c = min(max(t.y0 + 1, 0), p.h - 1);
-            const size_t o_nw = (size_t)y0c * p.w + x0c, o_ne = (size_t)y0c * p.w + x1c;
-            const size_t o_sw = (size_t)y1c * p.w + x0c, o_se = (size_t)y1c * p.w + x1c;
-
-            float c = 0.f;
-            if (in_nw || in_ne || in_sw || in_se) {
+            // quads with at least one tap inside the image live entirely inside the zero-bordered
+            // (h+2)x(w+2) source maps, so no per-tap bounds checks are needed (zeros padding,
+            // homography.py:150-152); everything else contributes exactly 0 with a closed gate.
+            const bool inwin = (t.x0 >= -1) && (t.x0 <= p.w - 1) && (t.y0 >= -1) && (t.y0 <= p.h - 1);
+            float c = 0.f, mu_w = 0.f, sg_w = 0.f;
+            if (inwin) {
+                const size_t o_nw = (size_t)(t.y0 + 1) * Wp + (t.x0 + 1);
+                const size_t o_ne = o_nw + 1, o_sw = o_nw + Wp, o_se = o_nw + Wp + 1;
                 float lvl0 = 0.f, lvl1 = 0.f, lvl2 = 0.f;          // ATen cascade sum (homography.py:155)
                 for (int f0 = 0; f0 < p.F; f0 += FeatChunk<FeatT>::N) {
                     FeatChunk<FeatT> cr, ca, cb, cc, cd;
                     cr.load(ref + f0);
-                    if (in_nw) ca.load(src + o_nw * p.F + f0); else ca.zero();
-                    if (in_ne) cb.load(src + o_ne * p.F + f0); else cb.zero();
-                    if (in_sw) cc.load(src + o_sw * p.F + f0); else cc.zero();
-                    if (in_se) cd.load(src + o_se * p.F + f0); else cd.zero();
+                    ca.load(src + o_nw * p.F + f0);
+                    cb.load(src + o_ne * p.F + f0);
+                    cc.load(src + o_sw * p.F + f0);
+                    cd.load(src + o_se * p.F + f0);
 #pragma unroll
                     for (int q = 0; q < FeatChunk<FeatT>::N; ++q) {
                         const float wv = bilerp(ca.v[q], cb.v[q], cc.v[q], cd.v[q], t);
@@ -124,11 +121,9 @@ __global__ __launch_bounds__(256) void cv_generic_kernel(const CvParams p) {
                     }
                 }
                 c = (lvl0 + lvl1) + lvl2;
+                mu_w = bilerp(sgm[o_nw * 2], sgm[o_ne * 2], sgm[o_sw * 2], sgm[o_se * 2], t);
+                sg_w = bilerp(sgm[o_nw * 2 + 1], sgm[o_ne * 2 + 1], sgm[o_sw * 2 + 1], sgm[o_se * 2 + 1], t);
             }
-            const float mu_w = bilerp(in_nw ? smu[o_nw] : 0.f, in_ne ? smu[o_ne] : 0.f,
-                                      in_sw ? smu[o_sw] : 0.f, in_se ? smu[o_se] : 0.f, t);
-            const float sg_w = bilerp(in_nw ? ssg[o_nw] : 0.f, in_ne ? ssg[o_ne] : 0.f,
-                                      in_sw ? ssg[o_sw] : 0.f, in_se ? ssg[o_se] : 0.f, t);
             const bool gate = __builtin_fabsf(zw - mu_w) < sg_w * p.kappa;   // homography.py:157-158
             acc += (double)c * (gate ? 1.0 : 0.0);                           // fp64 view sum, :159,116
         }

@@ -17,8 +17,8 @@ struct CvParams {
     int feat_bf16;
     float kappa;
     const void*    ref_feat;
-    const void*    src_feat;
-    const float*   src_gmm;
+    const void*    src_feat;          // (V*B, h+2, w+2, F) channel-last, one-texel zero border
+    const float*   src_gmm;           // (V*B, h+2, w+2, 2) interleaved [mu,sigma], one-texel zero border
     const float*   ref_gmm;
     const float*   d_volume;
     const float*   poses;
@@ -56,6 +56,6 @@ __device__ __forceinline__ void tile_of_block(const CvParams& p, int& tile, int&
 }
 
 hipError_t launch_cv_generic(const CvParams& p, hipStream_t stream);
-hipError_t launch_cv_window(const CvParams& p, hipStream_t stream, bool* handled);
+hipError_t launch_cv_worklist(const CvParams& p, hipStream_t stream, bool* handled);
 
 }  // namespace magnet

@@ -13,7 +13,7 @@ namespace magnet {
 constexpr int PK_PIX = 64;
 template <typename OutT, int FT>
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ in, OutT* __restrict__ out,
-                                                    int F, int hw, int blocks_per_img) {
+                                                    int F, int hw, int blocks_per_img, int w, int pad) {
     __shared__ float tile[FT][PK_PIX + 1];
     const int n = blockIdx.x / blocks_per_img;
     const int p0 = (blockIdx.x % blocks_per_img) * PK_PIX;
@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ in,
         const int q = i / VPP, vc = (i % VPP) * VEC;
         const int pq = p0 + q;
         if (pq >= hw || f0 + vc >= F) continue;
-        OutT* dst = out + ((size_t)n * hw + pq) * F + f0 + vc;
+        // destination texel inside the (h+2*pad) x (w+2*pad) image
+        const int h_ = hw / w, py = pq / w, px_ = pq % w;
+        const size_t tex = (size_t)n * (h_ + 2 * pad) * (w + 2 * pad) + (size_t)(py + pad) * (w + 2 * pad) + (px_ + pad);
+        OutT* dst = out + tex * F + f0 + vc;
         if constexpr (sizeof(OutT) == 4) {
             float4 o = make_float4(tile[vc][q], tile[vc + 1][q], tile[vc + 2][q], tile[vc + 3][q]);
             *reinterpret_cast<float4*>(dst) = o;
@@ -46,13 +49,60 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ in,
     }
 }
 
-hipError_t launch_pack(const float* in, void* out, int N, int F, int h, int w, bool bf16, hipStream_t s) {
+// zero the one-texel border of (N, h+2, w+2, F) images: 16-byte vectors
+__global__ __launch_bounds__(256) void zero_border_kernel(uint4* __restrict__ out, int N, int h, int w, int vec_per_tex) {
+    const int Wp = w + 2, Hp = h + 2;
+    const int per_img = 2 * Wp + 2 * h;                      // border texels of one image
+    const size_t total = (size_t)N * per_img * vec_per_tex;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % vec_per_tex);
+        const size_t t = i / vec_per_tex;
+        const int n = (int)(t / per_img), k = (int)(t % per_img);
+        int y, x;
+        if (k < Wp) { y = 0; x = k; }
+        else if (k < 2 * Wp) { y = Hp - 1; x = k - Wp; }
+        else { const int m = k - 2 * Wp; y = 1 + (m >> 1); x = (m & 1) ? Wp - 1 : 0; }
+        out[(((size_t)n * Hp + y) * Wp + x) * vec_per_tex + c] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+// (N,2,h,w) planar [mu,sigma] -> (N,h+2,w+2,2) interleaved, zero border (one thread per padded texel)
+__global__ __launch_bounds__(256) void pack_gmm_kernel(const float* __restrict__ in, float2* __restrict__ out,
+                                                        int N, int h, int w) {
+    const int Wp = w + 2, Hp = h + 2;
+    const size_t total = (size_t)N * Hp * Wp;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % Wp) - 1, y = (int)((i / Wp) % Hp) - 1;
+    const size_t n = i / ((size_t)Wp * Hp);
+    float2 v = make_float2(0.f, 0.f);
+    if (x >= 0 && x < w && y >= 0 && y < h) {
+        const size_t hw = (size_t)h * w, o = (size_t)y * w + x;
+        v = make_float2(in[(n * 2 + 0) * hw + o], in[(n * 2 + 1) * hw + o]);
+    }
+    out[i] = v;
+}
+
+hipError_t launch_pack_gmm(const float* in, float* out, int N, int h, int w, hipStream_t s) {
+    const size_t total = (size_t)N * (h + 2) * (w + 2);
+    hipLaunchKernelGGL(pack_gmm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in,
+                       reinterpret_cast<float2*>(out), N, h, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(const float* in, void* out, int N, int F, int h, int w, bool bf16, int pad, hipStream_t s) {
     const int hw = h * w;
     const int bpi = (hw + PK_PIX - 1) / PK_PIX;
     constexpr int FT = 64;
     const dim3 grid((unsigned)(N * bpi), (unsigned)((F + FT - 1) / FT)), block(256);
-    if (bf16) hipLaunchKernelGGL((pack_kernel<uint16_t, FT>), grid, block, 0, s, in, (uint16_t*)out, F, hw, bpi);
-    else      hipLaunchKernelGGL((pack_kernel<float, FT>),    grid, block, 0, s, in, (float*)out, F, hw, bpi);
+    if (pad) {
+        const int vec_per_tex = F * (bf16 ? 2 : 4) / 16;
+        const size_t total = (size_t)N * (2 * (w + 2) + 2 * h) * vec_per_tex;
+        const unsigned nb = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(zero_border_kernel, dim3(nb), dim3(256), 0, s, reinterpret_cast<uint4*>(out), N, h, w, vec_per_tex);
+    }
+    if (bf16) hipLaunchKernelGGL((pack_kernel<uint16_t, FT>), grid, block, 0, s, in, (uint16_t*)out, F, hw, bpi, w, pad);
+    else      hipLaunchKernelGGL((pack_kernel<float, FT>),    grid, block, 0, s, in, (float*)out, F, hw, bpi, w, pad);
     return hipGetLastError();
 }
 

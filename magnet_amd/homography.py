@@ -80,9 +80,9 @@ class CostVolumeCW:
         self.fe = lib.feat_enum(feat_dtype)
         self.B, self.F, self.h, self.w = ref_feat.shape
         self.V = nghbr_feat.shape[0] // self.B
-        self.ref_cl = lib.pack_features(ref_feat.detach().float().contiguous(), self.fe)
-        self.src_cl = lib.pack_features(nghbr_feat.detach().float().contiguous(), self.fe)
-        self.src_gmm = nghbr_gmms.detach().float().contiguous()
+        self.ref_cl = lib.pack_features(ref_feat.detach().float().contiguous(), self.fe, pad=0)
+        self.src_pad = lib.pack_features(nghbr_feat.detach().float().contiguous(), self.fe, pad=1)
+        self.src_gmm_pad = lib.pack_gmm(nghbr_gmms.detach().float().contiguous())
         self.poses = nghbr_poses.detach().to(device=dev, dtype=torch.float32).contiguous()
         self.is_valid = _valid_to_device(is_valid, dev)
         self.intM = _to_device_cached(cam_intrins["intM"], dev, torch.float32, _INTRINS_CACHE)
@@ -99,7 +99,7 @@ class CostVolumeCW:
         if sink is not None:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        res = lib.cost_volume_cw(self.ref_cl, self.src_cl, self.src_gmm, self.poses, self.is_valid,
+        res = lib.cost_volume_cw(self.ref_cl, self.src_pad, self.src_gmm_pad, self.poses, self.is_valid,
                                  self.intM, self.rays, self.kappa, ref_gmm=ref_gmm, k_list=k_list,
                                  d_volume=d_volume, out=out, path=self.path, stats=stats)
         if sink is not None:

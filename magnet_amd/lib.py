@@ -19,6 +19,7 @@ FEAT_F32, FEAT_BF16 = 0, 1
 MAX_CANDIDATES = 256
 
 API_SYMBOLS = ("magnet_version", "magnet_last_error", "magnet_device_count", "magnet_pack_features",
+               "magnet_pack_gmm",
                "magnet_cost_volume_cw", "magnet_gaussian_update", "magnet_upsample_depth")
 
 
@@ -32,8 +33,8 @@ class MagnetCostVolumeArgs(ctypes.Structure):
         ("B", ctypes.c_int32), ("V", ctypes.c_int32), ("F", ctypes.c_int32), ("D", ctypes.c_int32),
         ("h", ctypes.c_int32), ("w", ctypes.c_int32),
         ("kappa", ctypes.c_float), ("feat_dtype", ctypes.c_int32),
-        ("ref_feat_cl", ctypes.c_void_p), ("src_feat_cl", ctypes.c_void_p),
-        ("src_gmm", ctypes.c_void_p), ("ref_gmm", ctypes.c_void_p),
+        ("ref_feat_cl", ctypes.c_void_p), ("src_feat_pad", ctypes.c_void_p),
+        ("src_gmm_pad", ctypes.c_void_p), ("ref_gmm", ctypes.c_void_p),
         ("k_list", ctypes.c_void_p), ("d_volume", ctypes.c_void_p),
         ("poses", ctypes.c_void_p), ("is_valid", ctypes.c_void_p),
         ("intM", ctypes.c_void_p), ("rays", ctypes.c_void_p),
@@ -61,7 +62,9 @@ def load() -> ctypes.CDLL:
     lib.magnet_last_error.restype = ctypes.c_char_p
     lib.magnet_device_count.restype = ctypes.c_int
     lib.magnet_pack_features.restype = ctypes.c_int
-    lib.magnet_pack_features.argtypes = [P, P, I, I, I, I, I, P]
+    lib.magnet_pack_features.argtypes = [P, P, I, I, I, I, I, I, P]
+    lib.magnet_pack_gmm.restype = ctypes.c_int
+    lib.magnet_pack_gmm.argtypes = [P, P, I, I, I, P]
     lib.magnet_cost_volume_cw.restype = ctypes.c_int
     lib.magnet_cost_volume_cw.argtypes = [ctypes.POINTER(MagnetCostVolumeArgs), P]
     lib.magnet_gaussian_update.restype = ctypes.c_int
@@ -106,45 +109,63 @@ def feat_enum(dtype) -> int:
     raise MagnetError(f"unsupported feature storage dtype {dtype!r} (fp32 or bf16)")
 
 
-def pack_features(feat_nchw: torch.Tensor, feat_dtype: int = FEAT_F32, out: torch.Tensor | None = None):
-    """(N,F,h,w) fp32 NCHW -> (N,h,w,F) channel-last in fp32 or bf16 storage."""
+def pack_features(feat_nchw: torch.Tensor, feat_dtype: int = FEAT_F32, pad: int = 0, out: torch.Tensor | None = None):
+    """(N,F,h,w) fp32 NCHW -> (N,h+2*pad,w+2*pad,F) channel-last in fp32 or bf16 storage; pad=1 adds a
+    one-texel zero border (the source-view layout of the matcher)."""
     x = _dev(feat_nchw, "feat_nchw", torch.float32)
     N, F, h, w = x.shape
+    shape = (N, h + 2 * pad, w + 2 * pad, F)
     if out is None:
-        out = torch.empty((N, h, w, F), dtype=feat_torch_dtype(feat_dtype), device=x.device)
+        out = torch.empty(shape, dtype=feat_torch_dtype(feat_dtype), device=x.device)
     else:
         _dev(out, "out", feat_torch_dtype(feat_dtype))
-        if tuple(out.shape) != (N, h, w, F):
-            raise MagnetError(f"out has shape {tuple(out.shape)}, expected {(N, h, w, F)}")
+        if tuple(out.shape) != shape:
+            raise MagnetError(f"out has shape {tuple(out.shape)}, expected {shape}")
     with torch.cuda.device(x.device):
-        _check(load().magnet_pack_features(x.data_ptr(), out.data_ptr(), N, F, h, w, feat_dtype, _stream(x)),
+        _check(load().magnet_pack_features(x.data_ptr(), out.data_ptr(), N, F, h, w, feat_dtype, int(pad), _stream(x)),
                "magnet_pack_features")
     return out
 
 
-def cost_volume_cw(ref_feat_cl, src_feat_cl, src_gmm, poses, is_valid, intM, rays, kappa,
+def pack_gmm(gmm_nchw: torch.Tensor, out: torch.Tensor | None = None):
+    """(N,2,h,w) fp32 [mu,sigma] planes -> (N,h+2,w+2,2) interleaved with a zero border."""
+    g = _dev(gmm_nchw, "gmm_nchw", torch.float32)
+    N, two, h, w = g.shape
+    if two != 2:
+        raise MagnetError(f"gmm_nchw must be (N,2,h,w), got {tuple(g.shape)}")
+    if out is None:
+        out = torch.empty((N, h + 2, w + 2, 2), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _check(load().magnet_pack_gmm(g.data_ptr(), _dev(out, "out", torch.float32).data_ptr(), N, h, w, _stream(g)),
+               "magnet_pack_gmm")
+    return out
+
+
+def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM, rays, kappa,
                    ref_gmm=None, k_list=None, d_volume=None, out=None, path: int = 0, stats=None):
     """Launch the fused matching kernel.  All tensors on one GPU; see MagnetCostVolumeArgs.
 
-    ref_feat_cl (B,h,w,F) / src_feat_cl (V*B,h,w,F): fp32 or bf16 channel-last (pack_features).
-    src_gmm (V*B,2,h,w), poses (B,V,4,4), is_valid (B,V) int32, intM (B,3,3), rays (B,3,h*w).
+    ref_feat_cl (B,h,w,F) from pack_features(pad=0); src_feat_pad (V*B,h+2,w+2,F) from
+    pack_features(pad=1) (fp32 or bf16, same dtype); src_gmm_pad (V*B,h+2,w+2,2) from pack_gmm;
+    poses (B,V,4,4), is_valid (B,V) int32, intM (B,3,3), rays (B,3,h*w).
     Either d_volume (B,D,h,w) or (ref_gmm (B,2,h,w), k_list: sequence of D python floats)."""
     r = _dev(ref_feat_cl, "ref_feat_cl")
-    s = _dev(src_feat_cl, "src_feat_cl", r.dtype)
+    s = _dev(src_feat_pad, "src_feat_pad", r.dtype)
     fe = feat_enum(r.dtype)
     B, h, w, F = r.shape
-    if s.shape[0] % B != 0 or tuple(s.shape[1:]) != (h, w, F):
-        raise MagnetError(f"src_feat_cl shape {tuple(s.shape)} does not match ref_feat_cl {tuple(r.shape)}")
+    if s.shape[0] % B != 0 or tuple(s.shape[1:]) != (h + 2, w + 2, F):
+        raise MagnetError(f"src_feat_pad shape {tuple(s.shape)} does not match ref_feat_cl {tuple(r.shape)} "
+                          "(expected (V*B, h+2, w+2, F))")
     V = s.shape[0] // B
     a = MagnetCostVolumeArgs()
     a.B, a.V, a.F, a.h, a.w = B, V, F, h, w
     a.kappa = float(kappa)
     a.feat_dtype = fe
-    a.ref_feat_cl, a.src_feat_cl = r.data_ptr(), s.data_ptr()
-    g = _dev(src_gmm, "src_gmm", torch.float32)
-    if tuple(g.shape) != (V * B, 2, h, w):
-        raise MagnetError(f"src_gmm shape {tuple(g.shape)}, expected {(V * B, 2, h, w)}")
-    a.src_gmm = g.data_ptr()
+    a.ref_feat_cl, a.src_feat_pad = r.data_ptr(), s.data_ptr()
+    g = _dev(src_gmm_pad, "src_gmm_pad", torch.float32)
+    if tuple(g.shape) != (V * B, h + 2, w + 2, 2):
+        raise MagnetError(f"src_gmm_pad shape {tuple(g.shape)}, expected {(V * B, h + 2, w + 2, 2)}")
+    a.src_gmm_pad = g.data_ptr()
     keep = [r, s, g]
     kbuf = None
     if d_volume is not None:

@@ -42,11 +42,24 @@ def cost_stats(hip, orc, atol=2e-5, rtol=2e-5):
                 max_abs=float(diff.max()), n=int(diff.size), finite=bool(np.isfinite(hip).all()))
 
 
-def assert_cost_parity(hip, orc, flip_frac=1e-5, atol=2e-5, rtol=2e-5, bitwise_frac=None, label=""):
-    st = cost_stats(hip, orc, atol, rtol)
-    print(f"[parity {label}] {st}")
+# Tolerances by kernel (include/magnet_hip.h `path`):
+#   path 1 (generic gather kernel): every operation mirrors the oracle -> BITWISE equality.
+#   path 0/2 (worklist kernel): gates and sample positions are still exactly the oracle's; the 64-channel
+#   sum is re-associated (dot products per tap, then the bilinear combine), so values agree to fp32
+#   accumulation noise: |d| <= 1e-4 + 1e-4*|oracle| (costs are O(1..10), sums of 64 products of
+#   N(0,1)-scale numbers), and NO entry may differ by more than that (gate flips would).
+WORKLIST_ATOL = 1e-4
+WORKLIST_RTOL = 1e-4
+
+
+def assert_cost_parity(hip, orc, path=0, flip_frac=0.0, label=""):
+    if path == 1:
+        st = cost_stats(hip, orc, 0.0, 0.0)
+        print(f"[parity {label} generic] {st}")
+        assert st["finite"] and st["frac_bitwise"] == 1.0, f"{label}: generic kernel not bitwise: {st}"
+        return st
+    st = cost_stats(hip, orc, WORKLIST_ATOL, WORKLIST_RTOL)
+    print(f"[parity {label} worklist] {st}")
     assert st["finite"], f"{label}: non-finite values in the HIP cost volume"
     assert st["frac_flip"] <= flip_frac, f"{label}: {st}"
-    if bitwise_frac is not None:
-        assert st["frac_bitwise"] >= bitwise_frac, f"{label}: {st}"
     return st

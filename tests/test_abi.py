@@ -54,14 +54,16 @@ def test_argument_errors_are_codes_not_crashes(hip_lib):
     assert b"NULL" in hip_lib.magnet_last_error()
     a = MagnetCostVolumeArgs()                                                  # all zero
     assert hip_lib.magnet_cost_volume_cw(ctypes.byref(a), None) == 1
-    assert hip_lib.magnet_pack_features(None, None, 1, 8, 4, 4, 0, None) == 1
-    assert hip_lib.magnet_pack_features(16, 16, 1, 7, 4, 4, 0, None) == 2       # MAGNET_E_DIM (F % 8)
-    assert hip_lib.magnet_pack_features(16, 16, 1, 8, 4, 4, 9, None) == 3       # MAGNET_E_DTYPE
-    assert hip_lib.magnet_pack_features(16, 24, 1, 8, 4, 4, 0, None) == 4       # MAGNET_E_ALIGN
+    assert hip_lib.magnet_pack_features(None, None, 1, 8, 4, 4, 0, 0, None) == 1
+    assert hip_lib.magnet_pack_features(16, 16, 1, 7, 4, 4, 0, 0, None) == 2       # MAGNET_E_DIM (F % 8)
+    assert hip_lib.magnet_pack_features(16, 16, 1, 8, 4, 4, 9, 0, None) == 3       # MAGNET_E_DTYPE
+    assert hip_lib.magnet_pack_features(16, 24, 1, 8, 4, 4, 0, 0, None) == 4
+    assert hip_lib.magnet_pack_features(16, 16, 1, 8, 4, 4, 0, 2, None) == 2       # pad in {0,1}
+    assert hip_lib.magnet_pack_gmm(None, 16, 1, 4, 4, None) == 1       # MAGNET_E_ALIGN
     assert hip_lib.magnet_gaussian_update(16, 16, 16, 0, 5, None) == 2
     assert hip_lib.magnet_upsample_depth(16, 16, 16, 1, 2, 4, 4, 3, None) == 2  # k must be 1,2,4,8
     # D over the limit
-    a.ref_feat_cl = a.src_feat_cl = a.src_gmm = a.poses = a.is_valid = a.intM = a.rays = a.cost = 16
+    a.ref_feat_cl = a.src_feat_pad = a.src_gmm_pad = a.poses = a.is_valid = a.intM = a.rays = a.cost = 16
     a.d_volume = 16
     a.B = a.V = a.h = a.w = 1; a.F = 8; a.D = 257
     assert hip_lib.magnet_cost_volume_cw(ctypes.byref(a), None) == 2

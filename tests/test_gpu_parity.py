@@ -36,14 +36,25 @@ def test_device_is_gfx950(hip_lib, gpu):
 # ---- pack ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(3, 8, 5, 7), (2, 64, 12, 16), (1, 64, 120, 160), (2, 72, 9, 33)])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_pack_features(hip_lib, gpu, shape, dtype):
+@pytest.mark.parametrize("pad", [0, 1])
+def test_pack_features(hip_lib, gpu, shape, dtype, pad):
     from magnet_amd import lib
     x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
-    got = lib.pack_features(x.to(gpu), lib.feat_enum(dtype)).cpu()
-    exp = x.permute(0, 2, 3, 1).contiguous()
+    out = torch.full((shape[0], shape[2] + 2 * pad, shape[3] + 2 * pad, shape[1]), 3.0,
+                     dtype=lib.feat_torch_dtype(lib.feat_enum(dtype)), device=gpu)     # poisoned: border must be zeroed
+    got = lib.pack_features(x.to(gpu), lib.feat_enum(dtype), pad=pad, out=out).cpu()
+    exp = torch.nn.functional.pad(x, (pad, pad, pad, pad)).permute(0, 2, 3, 1).contiguous()
     if dtype == "bf16":
         exp = exp.to(torch.bfloat16)
-    assert got.dtype == exp.dtype and torch.equal(got, exp)        # bit-exact (RNE for bf16)
+    assert got.dtype == exp.dtype and torch.equal(got, exp)        # bit-exact (RNE for bf16), zero border
+
+
+def test_pack_gmm(hip_lib, gpu):
+    from magnet_amd import lib
+    g = torch.rand(3, 2, 13, 21, generator=torch.Generator().manual_seed(2)) + 0.5
+    got = lib.pack_gmm(g.to(gpu)).cpu()
+    exp = torch.nn.functional.pad(g, (1, 1, 1, 1)).permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(got, exp)
 
 
 # ---- cost volume: golden (reference) vectors -------------------------------------------------------
@@ -55,7 +66,7 @@ def test_cost_volume_tiny_golden(hip_lib, gpu, golden, path, fused):
     k = list(golden["G1_k_D5"])
     dv = None if fused else torch.from_numpy(golden["G2_d_volume"])
     got = _hip_cost(inp, k, gpu, d_volume=dv, path=path)
-    assert_cost_parity(got, golden["G2_cost"], flip_frac=0.0, label=f"tiny path={path} fused={fused}")
+    assert_cost_parity(got, golden["G2_cost"], path=path, label=f"tiny fused={fused}")
 
 
 def test_cost_volume_reference_signature(hip_lib, gpu, golden):
@@ -69,14 +80,15 @@ def test_cost_volume_reference_signature(hip_lib, gpu, golden):
                                        d["nghbr_feat"], d["ref_gmms"], d["nghbr_gmms"], R, t,
                                        inp["is_valid"], inp["cam_intrins"], 5)
     assert got.shape == (2, 5, 12, 16) and got.dtype == torch.float32 and got.device.type == "cuda"
-    assert_cost_parity(got, golden["G2_cost"], flip_frac=0.0, label="reference signature")
+    assert_cost_parity(got, golden["G2_cost"], path=0, label="reference signature")
 
 
 def test_cost_volume_C1_golden_subsample(hip_lib, gpu, golden):
     wl = synth.WORKLOADS["C1"]
     inp = synth.make_inputs(wl, B=1, seed=0)
-    got = _hip_cost(inp, list(golden["G1_k_D16"]), gpu).cpu().numpy()
-    assert_cost_parity(got[:, :, ::5, ::7], golden["G2_C1_cost_sub"], flip_frac=2e-5, label="C1 golden")
+    for path in (0, 1):
+        got = _hip_cost(inp, list(golden["G1_k_D16"]), gpu, path=path).cpu().numpy()
+        assert_cost_parity(got[:, :, ::5, ::7], golden["G2_C1_cost_sub"], path=path, label="C1 golden")
 
 
 # ---- cost volume: oracle on seeded inputs ------------------------------------------------------------
@@ -99,7 +111,7 @@ def test_cost_volume_vs_oracle(hip_lib, gpu, name, wlname, B, seed, fdt, invalid
     k = oracle.depth_sampling(3, wl.D)
     orc = oracle_cost(inp, k)
     got = _hip_cost(inp, k, gpu, feat_dtype=fdt, path=path)
-    assert_cost_parity(got, orc, flip_frac=2e-5, label=f"{name} path={path}")
+    assert_cost_parity(got, orc, path=path, label=name)
 
 
 def test_cost_volume_kitti_wide_aspect(hip_lib, gpu):
@@ -108,8 +120,9 @@ def test_cost_volume_kitti_wide_aspect(hip_lib, gpu):
     inp = synth.make_inputs(wl, B=1, seed=0)
     k = oracle.depth_sampling(3, wl.D)
     orc = oracle_cost(inp, k)
-    got = _hip_cost(inp, k, gpu)
-    assert_cost_parity(got, orc, flip_frac=5e-5, label="C4 kitti")
+    for path in (0, 1):
+        got = _hip_cost(inp, k, gpu, path=path)
+        assert_cost_parity(got, orc, path=path, label="C4 kitti")
 
 
 def test_cost_volume_ragged_grid_and_odd_D(hip_lib, gpu):
@@ -120,14 +133,32 @@ def test_cost_volume_ragged_grid_and_odd_D(hip_lib, gpu):
     orc = oracle_cost(inp, k)
     for path in (0, 1):
         got = _hip_cost(inp, k, gpu, path=path)
-        assert_cost_parity(got, orc, flip_frac=0.0, label=f"ragged path={path}")
+        assert_cost_parity(got, orc, path=path, label="ragged")
 
 
 def test_cost_volume_all_views_invalid_is_zero(hip_lib, gpu):
     wl = synth.Workload("inv", "scannet", 12, 16, V=2, D=5, F=8)
     inp = synth.make_inputs(wl, B=1, seed=5, invalid=[(0, 0), (0, 1)])
-    got = _hip_cost(inp, oracle.depth_sampling(3, 5), gpu)
-    assert torch.count_nonzero(got) == 0
+    for path in (0, 1):
+        got = _hip_cost(inp, oracle.depth_sampling(3, 5), gpu, path=path)
+        assert torch.count_nonzero(got) == 0
+
+
+def test_kernel_selection_stats(hip_lib, gpu):
+    """path 0 runs the worklist kernel for D <= 128 and the generic kernel above; `stats` counts tiles."""
+    from magnet_amd.homography import CostVolumeCW
+    for D, which in ((16, 0), (130, 1)):
+        wl = synth.Workload("st", "scannet", 12, 16, V=2, D=D, F=8)
+        inp = synth.make_inputs(wl, B=2, seed=7)
+        d = to_dev(inp, gpu)
+        k = oracle.depth_sampling(3, D)
+        stats = torch.zeros(4, dtype=torch.int32, device=gpu)
+        cv = CostVolumeCW(d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"],
+                          d["cam_intrins"], 5)
+        got = cv(ref_gmm=d["ref_gmms"], k_list=k, stats=stats)
+        st = stats.cpu().tolist()
+        assert st[which] == 2 * 3 * 1 and st[1 - which] == 0, st       # B=2 frames x (12/4) x (16/16) tiles
+        assert_cost_parity(got, oracle_cost(inp, k), path=which, label=f"D={D}")
 
 
 def test_cost_volume_strided_output_into_gnet_buffer(hip_lib, gpu):
@@ -135,10 +166,11 @@ def test_cost_volume_strided_output_into_gnet_buffer(hip_lib, gpu):
     wl = synth.Workload("s", "scannet", 12, 16, V=2, D=5, F=8)
     inp = synth.make_inputs(wl, B=2, seed=6)
     k = oracle.depth_sampling(3, 5)
-    buf = torch.full((2, 5 + 3, 12, 16), 7.0, device=gpu)
-    _hip_cost(inp, k, gpu, out=buf[:, :5])
-    dense = _hip_cost(inp, k, gpu)
-    assert torch.equal(buf[:, :5], dense) and torch.all(buf[:, 5:] == 7.0)
+    for path in (0, 1):
+        buf = torch.full((2, 5 + 3, 12, 16), 7.0, device=gpu)
+        _hip_cost(inp, k, gpu, out=buf[:, :5], path=path)
+        dense = _hip_cost(inp, k, gpu, path=path)
+        assert torch.equal(buf[:, :5], dense) and torch.all(buf[:, 5:] == 7.0)
 
 
 def test_linearity_in_reference_features(hip_lib, gpu):
@@ -147,10 +179,11 @@ def test_linearity_in_reference_features(hip_lib, gpu):
     wl = synth.WORKLOADS["C2"]
     inp = synth.make_inputs(wl, B=1, seed=3)
     k = oracle.depth_sampling(3, wl.D)
-    a = _hip_cost(inp, k, gpu, feat_dtype="bf16")
-    inp2 = dict(inp); inp2["ref_feat"] = inp["ref_feat"] * 2.0
-    b = _hip_cost(inp2, k, gpu, feat_dtype="bf16")
-    assert torch.equal(b, a * 2.0)
+    for path in (0, 1):
+        a = _hip_cost(inp, k, gpu, feat_dtype="bf16", path=path)
+        inp2 = dict(inp); inp2["ref_feat"] = inp["ref_feat"] * 2.0
+        b = _hip_cost(inp2, k, gpu, feat_dtype="bf16", path=path)
+        assert torch.equal(b, a * 2.0)
 
 
 # ---- gaussian update / upsample ------------------------------------------------------------------------
