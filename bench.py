@@ -195,7 +195,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if fdt == "fp32" else "f32 (bf16-stored features)",
             "data": "synthetic",
-            "config": {"workload": f"{wl.name}: {wl.camera} {4 * wl.h}x{4 * wl.w} input -> {wl.h}x{wl.w} matching grid, "
+            "config": {"workload": f"{wl.name}: {wl.camera} " + (f"{4 * wl.h}x{4 * wl.w} input -> {wl.h}x{wl.w} matching grid, "
+                                                                     if not wl.name.endswith(("L", "Lf")) else
+                                                                     f"{wl.h}x{wl.w} matching grid (grid-stress variant), ") + f"
                                    f"V={wl.V} source views, D={wl.D} candidates, F={wl.F}, I={iters} iteration(s), "
                                    f"{fdt} feature storage",
                        "frames_per_gpu_per_step": B, "step": "kernel-only" if a.kernel_only else

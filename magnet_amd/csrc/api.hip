@@ -94,6 +94,7 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: grid too large");
     p.feat_bf16 = (a->feat_dtype == MAGNET_FEAT_BF16);
     p.kappa = a->kappa;
+    p.ablate = (a->path >> 8) & 0xff;
     p.ref_feat = a->ref_feat_cl; p.src_feat = a->src_feat_pad; p.src_gmm = a->src_gmm_pad;
     p.ref_gmm = a->ref_gmm; p.d_volume = a->d_volume; p.poses = a->poses; p.is_valid = a->is_valid;
     p.intM = a->intM; p.rays = a->rays; p.cost = a->cost; p.stats = a->stats;
@@ -105,12 +106,13 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
 
     hipError_t e = hipSuccess;
     bool handled = false;
-    if (a->path != 1) {
+    const int path = a->path & 0xff;
+    if (path != 1) {
         e = magnet::launch_cv_worklist(p, (hipStream_t)stream, &handled);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw worklist launch");
     }
     if (!handled) {
-        if (a->path == 2) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the worklist kernel does not take this shape (D > 128 or very wide F)");
+        if (path == 2) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the worklist kernel does not take this shape (D > 128 or very wide F)");
         e = magnet::launch_cv_generic(p, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw generic launch");
     }

@@ -91,14 +91,14 @@ __global__ __launch_bounds__(256) void cv_generic_kernel(const CvParams p) {
             const float* __restrict__ sgm = p.src_gmm + sidx * (size_t)Hp * Wp * 2;
             float ix, iy, zw;
             project(pv, gc, d, ix, iy, zw);
-            const Taps t = make_taps(ix, iy);
+            int qx0, qy0; bool inwin;
+            const Taps t = make_taps(ix, iy, (float)p.w, (float)p.h, qx0, qy0, inwin);
             // quads with at least one tap inside the image live entirely inside the zero-bordered
             // (h+2)x(w+2) source maps, so no per-tap bounds checks are needed (zeros padding,
             // homography.py:150-152); everything else contributes exactly 0 with a closed gate.
-            const bool inwin = (t.x0 >= -1) && (t.x0 <= p.w - 1) && (t.y0 >= -1) && (t.y0 <= p.h - 1);
             float c = 0.f, mu_w = 0.f, sg_w = 0.f;
             if (inwin) {
-                const size_t o_nw = (size_t)(t.y0 + 1) * Wp + (t.x0 + 1);
+                const size_t o_nw = (size_t)(qy0 + 1) * Wp + (qx0 + 1);
                 const size_t o_ne = o_nw + 1, o_sw = o_nw + Wp, o_se = o_nw + Wp + 1;
                 float lvl0 = 0.f, lvl1 = 0.f, lvl2 = 0.f;          // ATen cascade sum (homography.py:155)
                 for (int f0 = 0; f0 < p.F; f0 += FeatChunk<FeatT>::N) {

@@ -15,6 +15,7 @@ struct CvParams {
     int B, V, F, D, h, w;
     int tiles_x, tiles_y;
     int feat_bf16;
+    int ablate;                       // dev-only timing ablations (path >> 8): 1 = skip P2 dots, 2 = skip gmm taps
     float kappa;
     const void*    ref_feat;
     const void*    src_feat;          // (V*B, h+2, w+2, F) channel-last, one-texel zero border
@@ -35,6 +36,8 @@ __device__ __forceinline__ GridConst grid_const(const CvParams& p) {
     GridConst gc;
     gc.cw = (float)((double)p.w / 2.0);
     gc.ch = (float)((double)p.h / 2.0);
+    gc.rcw = 1.0f / gc.cw;
+    gc.rch = 1.0f / gc.ch;
     gc.sw = (float)p.w / 2.0f;
     gc.sh = (float)p.h / 2.0f;
     return gc;

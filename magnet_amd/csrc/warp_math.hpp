@@ -57,19 +57,28 @@ __device__ __forceinline__ PixelView make_pixel_view(const float* __restrict__ K
 // Grid constants shared by every sample of a launch.
 struct GridConst {
     float cw, ch;     // w/2, h/2 (the reference's u_center, v_center)
+    float rcw, rch;   // RN(1/cw), RN(1/ch) for the exact constant division below
     float sw, sh;     // ATen scaling_factor = size/2
 };
 
+// x / c for a launch constant c, correctly rounded (== IEEE division) in 3 operations:
+// q = x*rc; r = x - q*c (exact, fused); q' = q + r*rc (fused)   [Markstein; rc = RN(1/c)].
+__device__ __forceinline__ float div_const(float x, float c, float rc) {
+    const float q = x * rc;
+    const float r = __builtin_fmaf(-q, c, x);
+    return __builtin_fmaf(r, rc, q);
+}
+
 struct Taps {
     float nw, ne, sw, se;  // bilinear weights, ATen order
-    int   x0, y0;          // integer origin of the 2x2 quad (far out of range when not finite)
 };
 
 __device__ __forceinline__ float clamp10(float g) {
-    // reference: coords[coords > 10] = 10; coords[coords < -10] = -10  (NaN passes through)
-    g = (g > 10.0f) ? 10.0f : g;
-    g = (g < -10.0f) ? -10.0f : g;
-    return g;
+    // reference: coords[coords > 10] = 10; coords[coords < -10] = -10 (homography.py:147-148).
+    // One v_med3_f32.  For finite g it is exactly that clamp.  The reference lets a NaN pass through
+    // (-> a NaN sample position, which grid_sample treats as out of range); v_med3 maps NaN to one
+    // of the bounds instead, i.e. to a position 4.5 images outside: the same all-zero sample.
+    return __builtin_amdgcn_fmed3f(g, -10.0f, 10.0f);
 }
 
 // Sample position in texel units and the warped depth for candidate depth d.
@@ -79,16 +88,28 @@ __device__ __forceinline__ void project(const PixelView& pv, const GridConst& gc
     float Py = pv.kt1 + pv.rpy * d;
     const float Pz = pv.kt2 + pv.rpz * d;
     const float zz = Pz + 1e-10f;
-    Px = Px / zz;
-    Py = Py / zz;
+    // Px/zz and Py/zz, correctly rounded (== the reference's IEEE divisions) from ONE hardware
+    // reciprocal: r1 = Newton-refined v_rcp_f32 (1 ulp -> ~RN(1/zz)), then per quotient
+    // q = P*r1; rem = P - q*zz (exact, fused); q' = q + rem*r1 (fused).  9 operations instead of the
+    // ~22 of two full division expansions; bit-equality with IEEE division is asserted by the
+    // generic kernel's bitwise parity tests (and was checked on 2e7 random operands on the host).
+    // A zero/denormal/overflowing denominator yields NaN/inf here and +-inf there: both end up
+    // out of the image (make_taps), i.e. the same zero contribution.
+    const float r0 = __builtin_amdgcn_rcpf(zz);
+    const float e  = __builtin_fmaf(-zz, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e, r0, r0);
+    const float qx = Px * r1, qy = Py * r1;
+    Px = __builtin_fmaf(__builtin_fmaf(-qx, zz, Px), r1, qx);
+    Py = __builtin_fmaf(__builtin_fmaf(-qy, zz, Py), r1, qy);
     zw = pv.tz + pv.rcz * d;
-    const float gx = clamp10((Px - gc.cw) / gc.cw);
-    const float gy = clamp10((Py - gc.ch) / gc.ch);
+    const float gx = clamp10(div_const(Px - gc.cw, gc.cw, gc.rcw));
+    const float gy = clamp10(div_const(Py - gc.ch, gc.ch, gc.rch));
     ix = __builtin_fmaf(gx + 1.0f, gc.sw, -0.5f);
     iy = __builtin_fmaf(gy + 1.0f, gc.sh, -0.5f);
 }
 
-__device__ __forceinline__ Taps make_taps(float ix, float iy) {
+// Weights + quad origin; inwin: at least one tap may lie inside the image (x0 in [-1,w-1], y0 in [-1,h-1]).
+__device__ __forceinline__ Taps make_taps(float ix, float iy, float fw, float fh, int& qx0, int& qy0, bool& inwin) {
     Taps t;
     const float x0 = __builtin_floorf(ix), y0 = __builtin_floorf(iy);
     const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
@@ -96,10 +117,11 @@ __device__ __forceinline__ Taps make_taps(float ix, float iy) {
     t.ne = (ix - x0) * (y1 - iy);
     t.sw = (x1 - ix) * (iy - y0);
     t.se = (ix - x0) * (iy - y0);
-    // the +-10 clamp bounds |ix|,|iy| by 5.5*size; anything else is NaN/garbage -> out of range
-    const bool finite = (__builtin_fabsf(ix) < 1e9f) && (__builtin_fabsf(iy) < 1e9f);
-    t.x0 = finite ? (int)x0 : -100000;
-    t.y0 = finite ? (int)y0 : -100000;
+    // floor(ix) in [-1, w-1]  <=>  -1 <= ix < w ; comparisons are false for NaN, and the +-10 clamp
+    // bounds |ix|,|iy| by 5.5*size, so the int conversions below cannot overflow when inwin holds
+    inwin = (ix >= -1.0f) && (ix < fw) && (iy >= -1.0f) && (iy < fh);
+    qx0 = (int)x0;
+    qy0 = (int)y0;
     return t;
 }
 

@@ -46,10 +46,10 @@ def cost_stats(hip, orc, atol=2e-5, rtol=2e-5):
 #   path 1 (generic gather kernel): every operation mirrors the oracle -> BITWISE equality.
 #   path 0/2 (worklist kernel): gates and sample positions are still exactly the oracle's; the 64-channel
 #   sum is re-associated (dot products per tap, then the bilinear combine), so values agree to fp32
-#   accumulation noise: |d| <= 1e-4 + 1e-4*|oracle| (costs are O(1..10), sums of 64 products of
+#   accumulation noise: |d| <= 2e-5 + 2e-5*|oracle| (costs are O(1..10), sums of 64 products of
 #   N(0,1)-scale numbers), and NO entry may differ by more than that (gate flips would).
-WORKLIST_ATOL = 1e-4
-WORKLIST_RTOL = 1e-4
+WORKLIST_ATOL = 2e-5      # measured on MI355X: max |d| 3.8e-6 over all test shapes
+WORKLIST_RTOL = 2e-5
 
 
 def assert_cost_parity(hip, orc, path=0, flip_frac=0.0, label=""):
