@@ -188,6 +188,10 @@ def main():
     frames = world * B * a.steps
 
     if rank == 0:
+        grid_desc = (f"{wl.h}x{wl.w} matching grid (grid-stress variant)" if wl.name.endswith(("L", "Lf"))
+                     else f"{4 * wl.h}x{4 * wl.w} input -> {wl.h}x{wl.w} matching grid")
+        workload_desc = (f"{wl.name}: {wl.camera} {grid_desc}, V={wl.V} source views, D={wl.D} candidates, "
+                         f"F={wl.F}, I={iters} iteration(s), {fdt} feature storage")
         res = {
             "metric": "ref-frames/sec (640x480, 4 src, 64 cand) + warp-kernel HBM GB/s",
             "value": frames / elapsed, "unit": "ref-frames/s",
@@ -195,11 +199,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if fdt == "fp32" else "f32 (bf16-stored features)",
             "data": "synthetic",
-            "config": {"workload": f"{wl.name}: {wl.camera} " + (f"{4 * wl.h}x{4 * wl.w} input -> {wl.h}x{wl.w} matching grid, "
-                                                                     if not wl.name.endswith(("L", "Lf")) else
-                                                                     f"{wl.h}x{wl.w} matching grid (grid-stress variant), ") + f"
-                                   f"V={wl.V} source views, D={wl.D} candidates, F={wl.F}, I={iters} iteration(s), "
-                                   f"{fdt} feature storage",
+            "config": {"workload": workload_desc,
                        "frames_per_gpu_per_step": B, "step": "kernel-only" if a.kernel_only else
                        "pack + I x (fused cost volume + G-Net(MIOpen) + Gaussian update) + mask head + convex upsample",
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; "
