@@ -72,10 +72,11 @@ typedef struct MagnetCostVolumeArgs {
     const float   *intM;                   /* (B,3,3) intrinsics at grid resolution */
     const float   *rays;                   /* (B,3,h*w) unit_ray_array_2D */
     float         *cost;                   /* OUT (B,D,h,w) fp32; frame b starts at cost + b*cost_batch_stride */
-    int32_t        path;                   /* 0 = auto (worklist kernel when the shape allows); 1 = force the generic
-                                              (bit-exact) gather kernel; 2 = require the worklist kernel */
-    uint32_t      *stats;                  /* optional device uint32[4]: {tiles run by the worklist kernel, tiles run by
-                                              the generic kernel, 0, 0}, accumulated with atomics; NULL = off */
+    int32_t        path;                   /* kernel selection: 0 = auto (candidate-lane kernel; generic for shapes it
+                                              does not take); 1 = generic gather kernel (bit-exact reference path);
+                                              2 = candidate-lane kernel or error; 3 = pixel-lane worklist kernel */
+    uint32_t      *stats;                  /* optional device uint32[4]: {tiles run by a fast kernel, tiles run by the
+                                              generic kernel, items (distinct open quads) correlated, 0}, accumulated with atomics; NULL = off */
     int64_t        cost_batch_stride;      /* elements between consecutive frames of `cost`; 0 = D*h*w (dense).
                                               Lets the kernel write the first D channels of G-Net's
                                               (B, D+256, h, w) input directly (models/MAGNET.py:167). */

@@ -107,12 +107,20 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
     hipError_t e = hipSuccess;
     bool handled = false;
     const int path = a->path & 0xff;
-    if (path != 1) {
+    if (path == 0 || path == 2) {
+        e = magnet::launch_cv_cand(p, (hipStream_t)stream, &handled);
+        if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw candidate-lane launch");
+        if (!handled && path == 2)
+            return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the candidate-lane kernel does not take this shape");
+    } else if (path == 3) {
         e = magnet::launch_cv_worklist(p, (hipStream_t)stream, &handled);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw worklist launch");
+        if (!handled)
+            return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the worklist kernel does not take this shape (D > 128 or very wide F)");
+    } else if (path != 1) {
+        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: unknown path %d", path);
     }
     if (!handled) {
-        if (path == 2) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the worklist kernel does not take this shape (D > 128 or very wide F)");
         e = magnet::launch_cv_generic(p, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw generic launch");
     }

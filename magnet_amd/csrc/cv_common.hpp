@@ -60,5 +60,6 @@ __device__ __forceinline__ void tile_of_block(const CvParams& p, int& tile, int&
 
 hipError_t launch_cv_generic(const CvParams& p, hipStream_t stream);
 hipError_t launch_cv_worklist(const CvParams& p, hipStream_t stream, bool* handled);
+hipError_t launch_cv_cand(const CvParams& p, hipStream_t stream, bool* handled);
 
 }  // namespace magnet

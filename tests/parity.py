@@ -44,7 +44,7 @@ def cost_stats(hip, orc, atol=2e-5, rtol=2e-5):
 
 # Tolerances by kernel (include/magnet_hip.h `path`):
 #   path 1 (generic gather kernel): every operation mirrors the oracle -> BITWISE equality.
-#   path 0/2 (worklist kernel): gates and sample positions are still exactly the oracle's; the 64-channel
+#   path 0/2 (candidate-lane kernel) and 3 (worklist kernel): gates and sample positions are still exactly the oracle's; the 64-channel
 #   sum is re-associated (dot products per tap, then the bilinear combine), so values agree to fp32
 #   accumulation noise: |d| <= 2e-5 + 2e-5*|oracle| (costs are O(1..10), sums of 64 products of
 #   N(0,1)-scale numbers), and NO entry may differ by more than that (gate flips would).
@@ -59,7 +59,7 @@ def assert_cost_parity(hip, orc, path=0, flip_frac=0.0, label=""):
         assert st["finite"] and st["frac_bitwise"] == 1.0, f"{label}: generic kernel not bitwise: {st}"
         return st
     st = cost_stats(hip, orc, WORKLIST_ATOL, WORKLIST_RTOL)
-    print(f"[parity {label} worklist] {st}")
+    print(f"[parity {label} fast(path={path})] {st}")
     assert st["finite"], f"{label}: non-finite values in the HIP cost volume"
     assert st["frac_flip"] <= flip_frac, f"{label}: {st}"
     return st

@@ -58,7 +58,7 @@ def test_pack_gmm(hip_lib, gpu):
 
 
 # ---- cost volume: golden (reference) vectors -------------------------------------------------------
-@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("path", [0, 1, 3])
 @pytest.mark.parametrize("fused", [True, False])
 def test_cost_volume_tiny_golden(hip_lib, gpu, golden, path, fused):
     """The reference's own output on the edge-case vector (invalid view, behind-camera pose, OOB)."""
@@ -86,7 +86,7 @@ def test_cost_volume_reference_signature(hip_lib, gpu, golden):
 def test_cost_volume_C1_golden_subsample(hip_lib, gpu, golden):
     wl = synth.WORKLOADS["C1"]
     inp = synth.make_inputs(wl, B=1, seed=0)
-    for path in (0, 1):
+    for path in (0, 1, 3):
         got = _hip_cost(inp, list(golden["G1_k_D16"]), gpu, path=path).cpu().numpy()
         assert_cost_parity(got[:, :, ::5, ::7], golden["G2_C1_cost_sub"], path=path, label="C1 golden")
 
@@ -103,7 +103,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("path", [0, 1, 3])
 @pytest.mark.parametrize("name,wlname,B,seed,fdt,invalid", CASES)
 def test_cost_volume_vs_oracle(hip_lib, gpu, name, wlname, B, seed, fdt, invalid, path):
     wl = synth.WORKLOADS[wlname]
@@ -120,7 +120,7 @@ def test_cost_volume_kitti_wide_aspect(hip_lib, gpu):
     inp = synth.make_inputs(wl, B=1, seed=0)
     k = oracle.depth_sampling(3, wl.D)
     orc = oracle_cost(inp, k)
-    for path in (0, 1):
+    for path in (0, 1, 3):
         got = _hip_cost(inp, k, gpu, path=path)
         assert_cost_parity(got, orc, path=path, label="C4 kitti")
 
@@ -131,7 +131,7 @@ def test_cost_volume_ragged_grid_and_odd_D(hip_lib, gpu):
     inp = synth.make_inputs(wl, B=3, seed=4)
     k = oracle.depth_sampling(3, wl.D)
     orc = oracle_cost(inp, k)
-    for path in (0, 1):
+    for path in (0, 1, 3):
         got = _hip_cost(inp, k, gpu, path=path)
         assert_cost_parity(got, orc, path=path, label="ragged")
 
@@ -139,26 +139,34 @@ def test_cost_volume_ragged_grid_and_odd_D(hip_lib, gpu):
 def test_cost_volume_all_views_invalid_is_zero(hip_lib, gpu):
     wl = synth.Workload("inv", "scannet", 12, 16, V=2, D=5, F=8)
     inp = synth.make_inputs(wl, B=1, seed=5, invalid=[(0, 0), (0, 1)])
-    for path in (0, 1):
+    for path in (0, 1, 3):
         got = _hip_cost(inp, oracle.depth_sampling(3, 5), gpu, path=path)
         assert torch.count_nonzero(got) == 0
 
 
 def test_kernel_selection_stats(hip_lib, gpu):
-    """path 0 runs the worklist kernel for D <= 128 and the generic kernel above; `stats` counts tiles."""
+    """path 0 = candidate-lane kernel for every D (several candidate blocks above 64), path 3 = worklist
+    kernel up to D = 128, path 1 = generic; `stats` counts tiles per kernel class."""
+    from magnet_amd import lib
     from magnet_amd.homography import CostVolumeCW
-    for D, which in ((16, 0), (130, 1)):
+    for D, path, which in ((16, 0, 0), (130, 0, 0), (130, 1, 1), (100, 3, 0), (7, 2, 0)):
         wl = synth.Workload("st", "scannet", 12, 16, V=2, D=D, F=8)
         inp = synth.make_inputs(wl, B=2, seed=7)
         d = to_dev(inp, gpu)
         k = oracle.depth_sampling(3, D)
         stats = torch.zeros(4, dtype=torch.int32, device=gpu)
         cv = CostVolumeCW(d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"],
-                          d["cam_intrins"], 5)
+                          d["cam_intrins"], 5, path=path)
         got = cv(ref_gmm=d["ref_gmms"], k_list=k, stats=stats)
         st = stats.cpu().tolist()
-        assert st[which] == 2 * 3 * 1 and st[1 - which] == 0, st       # B=2 frames x (12/4) x (16/16) tiles
-        assert_cost_parity(got, oracle_cost(inp, k), path=which, label=f"D={D}")
+        assert st[which] == 2 * 3 * 1 and st[1 - which] == 0, (D, path, st)   # B=2 frames x (12/4) x (16/16) tiles
+        assert_cost_parity(got, oracle_cost(inp, k), path=path, label=f"D={D} path={path}")
+    wl = synth.Workload("st", "scannet", 12, 16, V=2, D=130, F=8)
+    inp = synth.make_inputs(wl, B=1, seed=7); d = to_dev(inp, gpu)
+    cv = CostVolumeCW(d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"],
+                      d["cam_intrins"], 5, path=3)
+    with pytest.raises(lib.MagnetError, match="worklist kernel does not take"):
+        cv(ref_gmm=d["ref_gmms"], k_list=oracle.depth_sampling(3, 130))
 
 
 def test_cost_volume_strided_output_into_gnet_buffer(hip_lib, gpu):
@@ -166,7 +174,7 @@ def test_cost_volume_strided_output_into_gnet_buffer(hip_lib, gpu):
     wl = synth.Workload("s", "scannet", 12, 16, V=2, D=5, F=8)
     inp = synth.make_inputs(wl, B=2, seed=6)
     k = oracle.depth_sampling(3, 5)
-    for path in (0, 1):
+    for path in (0, 1, 3):
         buf = torch.full((2, 5 + 3, 12, 16), 7.0, device=gpu)
         _hip_cost(inp, k, gpu, out=buf[:, :5], path=path)
         dense = _hip_cost(inp, k, gpu, path=path)
@@ -179,7 +187,7 @@ def test_linearity_in_reference_features(hip_lib, gpu):
     wl = synth.WORKLOADS["C2"]
     inp = synth.make_inputs(wl, B=1, seed=3)
     k = oracle.depth_sampling(3, wl.D)
-    for path in (0, 1):
+    for path in (0, 1, 3):
         a = _hip_cost(inp, k, gpu, feat_dtype="bf16", path=path)
         inp2 = dict(inp); inp2["ref_feat"] = inp["ref_feat"] * 2.0
         b = _hip_cost(inp2, k, gpu, feat_dtype="bf16", path=path)
