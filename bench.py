@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--iters", type=int, default=0, help="refinement iterations (0 = workload default)")
     ap.add_argument("--feat-dtype", default="", choices=["", "fp32", "bf16"])
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 generic gather kernel, 2 window/MFMA kernel")
+    ap.add_argument("--conv-backend", default="mfma", choices=["mfma", "torch"],
+                    help="g_net/mask_head convolutions: bf16x3 MFMA kernel (default) or nn.Conv2d on MIOpen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-only", action="store_true", help="step = the fused cost-volume kernel alone")
     a = ap.parse_args()
@@ -144,7 +146,8 @@ def main():
     # enough frames per step that one launch fills the chip and the working set exceeds the 256 MiB L3
     B = a.frames or max(1, min(64, int(round(1200e6 / max(wl.algorithmic_bytes(), 1)))))
     torch.manual_seed(1234)                               # every rank draws its own init; rank 0's wins below
-    model = MAGNET(make_args(wl, iters), d_net=_NoBackbone(), f_net=_NoBackbone(), feat_dtype=fdt)
+    model = MAGNET(make_args(wl, iters), d_net=_NoBackbone(), f_net=_NoBackbone(), feat_dtype=fdt,
+                   conv_backend=a.conv_backend)
     model_cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         import copy
@@ -212,7 +215,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload_desc,
                        "frames_per_gpu_per_step": B, "step": "kernel-only" if a.kernel_only else
-                       "pack + I x (fused cost volume + G-Net(MIOpen) + Gaussian update) + mask head + convex upsample",
+                       ("pack + I x (fused cost volume + G-Net + Gaussian update) + mask head + convex upsample; convs on "
+                        + ("the bf16x3 MFMA kernel" if a.conv_backend == "mfma" else "MIOpen fp32")),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; "
                                       f"one RCCL weight broadcast ({bcast_bytes} B)"},
             "roofline": {"bound": "hbm", "kernel": "fused sample+warp+score (magnet_cost_volume_cw)",

@@ -11,6 +11,8 @@
  *                               + the candidate sampling in front of it (models/MAGNET.py:153-156)
  *   magnet_gaussian_update   -> the element-wise tail of GNET.forward (models/MAGNET.py:60-69)
  *   magnet_upsample_depth    -> upsample_depth_via_mask       (models/MAGNET.py:15-27)
+ *   magnet_conv_mfma (+ magnet_pack_split, magnet_gaussian_update_cl, magnet_upsample_depth_cl)
+ *                            -> the g_net / mask_head nn.Conv2d stacks (models/MAGNET.py:51-56,111-116)
  *
  * Conventions
  *   - All data pointers are DEVICE pointers unless the comment says HOST.  Buffers are caller-owned;
@@ -108,6 +110,45 @@ MAGNET_API int magnet_gaussian_update(const float *gnet_out, const float *gmm_in
  * the 9 neighbours, zero padding.  k <= 8. */
 MAGNET_API int magnet_upsample_depth(const float *depth, const float *mask, float *out,
                           int32_t B, int32_t C, int32_t h, int32_t w, int32_t k, void *stream);
+
+/* ---- G-Net / mask-head convolutions on the bf16 matrix cores, bf16x3 split operands (fp32-grade) ----
+ * Replaces the nn.Conv2d stacks of models/MAGNET.py:51-56 (GNET.gnet) and :111-116 (mask_head).
+ * Activations live in ZERO-BORDERED channel-last buffers (B, h+2, w+2, C) stored as two bf16 planes
+ * (hi = bf16(x), lo = bf16(x - hi)); `rows` = B*(h+2)*(w+2) flattened positions; a 3x3 tap is the row
+ * offset dy*(w+2)+dx.  Border rows of the output hold unspecified finite values: read interior rows only.
+ * Weights: two bf16 planes of [taps][cout_pad][cin] (cin contiguous) — magnet_amd/convnet.py prepacks them
+ * from nn.Conv2d's [cout][cin][kh][kw]; bias fp32 [cout_pad] (zero in the padding).
+ * Limits: cin % 32 == 0; taps in {1, 9}; cout_pad a multiple of 128, or 144, or 16. */
+typedef struct MagnetConvArgs {
+    const void  *in_hi, *in_lo;            /* bf16 (rows, cin) */
+    const void  *w_hi, *w_lo;              /* bf16 (taps, cout_pad, cin) */
+    const float *bias;                     /* (cout_pad) */
+    void        *out_hi, *out_lo;          /* out_mode 0: bf16 (rows, cout_pad) planes */
+    float       *out_f32;                  /* out_mode 1: fp32 (rows, cout_pad) */
+    int64_t      rows;
+    int32_t      cin, cout_pad, taps, wp;  /* wp = w + 2 (row pitch of the padded grid) */
+    int32_t      relu, out_mode;
+    int32_t      in_ld;                    /* elements between input rows (0 = cin): lets a layer read a channel slice
+                                              of a wider buffer in place (pointer offset + in_ld) */
+} MagnetConvArgs;
+
+MAGNET_API int magnet_conv_mfma(const MagnetConvArgs *args, void *stream);
+
+/* fp32 NCHW (N, C, h, w) (image stride `in_img_stride` elements, 0 = C*h*w) -> the interior of the split-bf16
+ * padded channel-last buffer (N, h+2, w+2, ctot), channels [c_off, c_off+round_up(C,8)) (the round-up lanes are
+ * written as zeros).  c_off % 8 == 0.  The border must have been zeroed once by the caller (never written). */
+MAGNET_API int magnet_pack_split(const float *nchw, void *out_hi, void *out_lo, int32_t N, int32_t C, int32_t h,
+                                 int32_t w, int32_t ctot, int32_t c_off, int64_t in_img_stride, void *stream);
+
+/* G-Net tail on the conv kernel's fp32 output: o = gnet_out[(b, y+1, x+1), 0..1] of a (B, h+2, w+2, ld) buffer;
+ * gmm_out = [mu + o0*sigma, (elu(o1) + 1 + 1e-10)*sigma], all gmm tensors (B,2,h,w) fp32 (models/MAGNET.py:60-69). */
+MAGNET_API int magnet_gaussian_update_cl(const float *gnet_out_pad, int32_t ld, const float *gmm_in, float *gmm_out,
+                                         int32_t B, int32_t h, int32_t w, void *stream);
+
+/* Learned convex upsampling with the mask in the conv kernel's padded channel-last fp32 layout
+ * (B, h+2, w+2, ld), channel n*k*k + i*k + j as in models/MAGNET.py:19; depth (B,2,h,w) -> out (B,2,4h,4w); k = 4. */
+MAGNET_API int magnet_upsample_depth_cl(const float *depth, const float *mask_pad, int32_t ld, float *out,
+                                        int32_t B, int32_t h, int32_t w, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,116 @@
+"""Runs the reference's small conv stacks (GNET.gnet, mask_head — models/MAGNET.py:51-56,111-116:
+Conv3x3(pad 1)-ReLU-Conv1x1-ReLU-Conv1x1-ReLU-Conv1x1) on the bf16x3 MFMA kernel (csrc/conv_mfma.hip).
+
+Activations are zero-bordered channel-last buffers (B, h+2, w+2, C) kept as two bf16 planes (hi, lo); the
+weights of the nn.Conv2d modules are re-packed (and re-split) lazily whenever a parameter changes, so the
+module keeps its reference state_dict and stays trainable through the torch path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import lib
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def split_bf16(x: torch.Tensor):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def _cout_pad(c):
+    if c <= 16:
+        return 16
+    if c == 144:
+        return 144
+    return _round_up(c, 128)
+
+
+class ConvStackMFMA:
+    """`seq`: nn.Sequential of Conv2d / ReLU as in the reference.  `in_map`: how the first layer's input channels are
+    laid out in the (wider, 32-aligned) input buffer: list of (src_start, length, dst_start)."""
+
+    def __init__(self, seq: nn.Sequential, in_map=None):
+        self.layers = []
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            conv = mods[i]
+            if not isinstance(conv, nn.Conv2d):
+                raise lib.MagnetError(f"ConvStackMFMA: unexpected module {type(conv).__name__}")
+            k = conv.kernel_size
+            if k not in ((1, 1), (3, 3)) or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 or \
+                    conv.padding != ((k[0] - 1) // 2, (k[1] - 1) // 2):
+                raise lib.MagnetError("ConvStackMFMA supports 1x1 and 3x3 (pad 1) stride-1 convolutions")
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            self.layers.append((conv, relu))
+            i += 2 if relu else 1
+        self.in_map = in_map
+        self._packed = None
+        self._key = None
+
+    def cin_pad(self):
+        c0 = self.layers[0][0].in_channels
+        if self.in_map is None:
+            return _round_up(c0, 32)
+        return _round_up(max(d + n for _, n, d in self.in_map), 32)
+
+    def _params_key(self, device):
+        return tuple((p.data_ptr(), p._version) for conv, _ in self.layers for p in conv.parameters()) + (str(device),)
+
+    @torch.no_grad()
+    def packed(self, device):
+        key = self._params_key(device)
+        if self._packed is not None and self._key == key:
+            return self._packed
+        out = []
+        cin_p = self.cin_pad()
+        for li, (conv, relu) in enumerate(self.layers):
+            W = conv.weight.detach().to(device=device, dtype=torch.float32)          # (Cout, Cin, kh, kw)
+            cout, cin, kh, kw = W.shape
+            cp = _cout_pad(cout)
+            Wp = torch.zeros((kh * kw, cp, cin_p), dtype=torch.float32, device=device)
+            Wt = W.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)                   # (tap, Cout, Cin)
+            if li == 0 and self.in_map is not None:
+                for src, n, dst in self.in_map:
+                    Wp[:, :cout, dst:dst + n] = Wt[:, :, src:src + n]
+            else:
+                Wp[:, :cout, :cin] = Wt
+            bias = torch.zeros(cp, dtype=torch.float32, device=device)
+            if conv.bias is not None:
+                bias[:cout] = conv.bias.detach().to(device=device, dtype=torch.float32)
+            hi, lo = split_bf16(Wp)
+            out.append(dict(w_hi=hi, w_lo=lo, bias=bias, taps=kh * kw, cin=cin_p, cout=cout, cout_pad=cp, relu=relu))
+            cin_p = cp                                                                 # next layer reads all padded channels
+            if li + 1 < len(self.layers) and cp % 32 != 0:
+                raise lib.MagnetError("hidden layer width must be a multiple of 32")
+        self._packed, self._key = out, key
+        return out
+
+    def run(self, in_hi, in_lo, in_ld, rows, wp, work):
+        """in_hi/in_lo: bf16 views whose data_ptr is row 0, channel 0 of this stack's input; `work`: dict for cached
+        hidden buffers.  Returns (fp32 tensor (rows, cout_pad_last), cout_pad_last)."""
+        packs = self.packed(in_hi.device)
+        cur_hi, cur_lo, cur_ld = in_hi, in_lo, in_ld
+        for li, pk in enumerate(packs):
+            last = li == len(packs) - 1
+            if last:
+                key = ("out", rows, pk["cout_pad"])
+                if key not in work:
+                    work[key] = torch.empty((rows, pk["cout_pad"]), dtype=torch.float32, device=in_hi.device)
+                lib.conv_mfma(cur_hi, cur_lo, cur_ld, pk["cin"], pk["w_hi"], pk["w_lo"], pk["bias"], pk["taps"], wp,
+                              pk["relu"], rows, out_f32=work[key])
+                return work[key], pk["cout_pad"]
+            key = ("hid", li & 1, rows, pk["cout_pad"])
+            if key not in work:
+                work[key] = (torch.empty((rows, pk["cout_pad"]), dtype=torch.bfloat16, device=in_hi.device),
+                             torch.empty((rows, pk["cout_pad"]), dtype=torch.bfloat16, device=in_hi.device))
+            oh, ol = work[key]
+            lib.conv_mfma(cur_hi, cur_lo, cur_ld, pk["cin"], pk["w_hi"], pk["w_lo"], pk["bias"], pk["taps"], wp,
+                          pk["relu"], rows, out_hi=oh, out_lo=ol)
+            cur_hi, cur_lo, cur_ld = oh, ol, pk["cout_pad"]

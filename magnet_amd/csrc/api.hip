@@ -11,6 +11,20 @@ hipError_t launch_pack(const float*, void*, int, int, int, int, bool, int, hipSt
 hipError_t launch_pack_gmm(const float*, float*, int, int, int, hipStream_t);
 hipError_t launch_gaussian_update(const float*, const float*, float*, int, int, hipStream_t);
 hipError_t launch_upsample(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+struct ConvParams {
+    const uint16_t* in_hi;  const uint16_t* in_lo;
+    const uint16_t* w_hi;   const uint16_t* w_lo;
+    const float*    bias;
+    uint16_t* out_hi; uint16_t* out_lo;
+    float*    out_f32;
+    long long rows;
+    int cin, cout_pad, taps, wp, relu, out_mode;
+    int in_ld;
+};
+hipError_t launch_conv_mfma(const ConvParams&, hipStream_t);
+hipError_t launch_pack_split(const float*, uint16_t*, uint16_t*, int, int, int, int, int, int, long long, hipStream_t);
+hipError_t launch_gaussian_update_cl(const float*, int, const float*, float*, int, int, int, hipStream_t);
+hipError_t launch_upsample_cl(const float*, const float*, int, float*, int, int, int, hipStream_t);
 }
 
 static thread_local char g_err[512] = "";
@@ -143,6 +157,59 @@ MAGNET_API int magnet_upsample_depth(const float* depth, const float* mask, floa
     if (k == 4 && !aligned16(out)) return fail(MAGNET_E_ALIGN, "magnet_upsample_depth: out not 16-byte aligned");
     hipError_t e = magnet::launch_upsample(depth, mask, out, B, C, h, w, k, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_upsample_depth launch");
+}
+
+MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
+    if (!a) return fail(MAGNET_E_NULL, "magnet_conv_mfma: args is NULL");
+    if (!a->in_hi || !a->in_lo || !a->w_hi || !a->w_lo || !a->bias) return fail(MAGNET_E_NULL, "magnet_conv_mfma: NULL input pointer");
+    if (a->out_mode == 0 ? (!a->out_hi || !a->out_lo) : !a->out_f32) return fail(MAGNET_E_NULL, "magnet_conv_mfma: NULL output pointer");
+    if (a->out_mode != 0 && a->out_mode != 1) return fail(MAGNET_E_DIM, "magnet_conv_mfma: out_mode must be 0 or 1");
+    if (a->rows <= 0 || a->cin <= 0 || (a->cin % 32) != 0) return fail(MAGNET_E_DIM, "magnet_conv_mfma: rows > 0 and cin %% 32 == 0 required (cin=%d)", a->cin);
+    if (a->taps != 1 && a->taps != 9) return fail(MAGNET_E_DIM, "magnet_conv_mfma: taps must be 1 or 9");
+    if (a->taps == 9 && a->wp < 3) return fail(MAGNET_E_DIM, "magnet_conv_mfma: wp (= w + 2) missing");
+    if (!((a->cout_pad > 0 && a->cout_pad % 128 == 0) || a->cout_pad == 144 || a->cout_pad == 16))
+        return fail(MAGNET_E_DIM, "magnet_conv_mfma: cout_pad=%d unsupported (multiple of 128, 144 or 16)", a->cout_pad);
+    if (!aligned16(a->in_hi) || !aligned16(a->in_lo) || !aligned16(a->w_hi) || !aligned16(a->w_lo) ||
+        (a->out_mode == 0 ? (!aligned16(a->out_hi) || !aligned16(a->out_lo)) : !aligned16(a->out_f32)))
+        return fail(MAGNET_E_ALIGN, "magnet_conv_mfma: pointers must be 16-byte aligned");
+    magnet::ConvParams p;
+    p.in_hi = (const uint16_t*)a->in_hi; p.in_lo = (const uint16_t*)a->in_lo;
+    p.w_hi = (const uint16_t*)a->w_hi; p.w_lo = (const uint16_t*)a->w_lo; p.bias = a->bias;
+    p.out_hi = (uint16_t*)a->out_hi; p.out_lo = (uint16_t*)a->out_lo; p.out_f32 = a->out_f32;
+    p.rows = a->rows; p.cin = a->cin; p.cout_pad = a->cout_pad; p.taps = a->taps; p.wp = a->wp;
+    p.relu = a->relu; p.out_mode = a->out_mode;
+    p.in_ld = a->in_ld ? a->in_ld : a->cin;
+    if (p.in_ld < a->cin || (p.in_ld % 8) != 0) return fail(MAGNET_E_DIM, "magnet_conv_mfma: in_ld=%d must be >= cin and a multiple of 8", p.in_ld);
+    hipError_t e = magnet::launch_conv_mfma(p, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_conv_mfma launch");
+}
+
+MAGNET_API int magnet_pack_split(const float* nchw, void* out_hi, void* out_lo, int32_t N, int32_t C, int32_t h, int32_t w,
+                                 int32_t ctot, int32_t c_off, int64_t in_img_stride, void* stream) {
+    if (!nchw || !out_hi || !out_lo) return fail(MAGNET_E_NULL, "magnet_pack_split: NULL pointer");
+    if (N <= 0 || C <= 0 || h <= 0 || w <= 0 || (c_off % 8) || c_off < 0 || c_off + ((C + 7) / 8) * 8 > ctot || (ctot % 8))
+        return fail(MAGNET_E_DIM, "magnet_pack_split: bad dims N=%d C=%d h=%d w=%d ctot=%d c_off=%d", N, C, h, w, ctot, c_off);
+    if (!aligned16(out_hi) || !aligned16(out_lo)) return fail(MAGNET_E_ALIGN, "magnet_pack_split: outputs not 16-byte aligned");
+    hipError_t e = magnet::launch_pack_split(nchw, (uint16_t*)out_hi, (uint16_t*)out_lo, N, C, h, w, ctot, c_off,
+                                             in_img_stride ? in_img_stride : (long long)C * h * w, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_pack_split launch");
+}
+
+MAGNET_API int magnet_gaussian_update_cl(const float* gnet_out_pad, int32_t ld, const float* gmm_in, float* gmm_out,
+                                         int32_t B, int32_t h, int32_t w, void* stream) {
+    if (!gnet_out_pad || !gmm_in || !gmm_out) return fail(MAGNET_E_NULL, "magnet_gaussian_update_cl: NULL pointer");
+    if (B <= 0 || h <= 0 || w <= 0 || ld < 2) return fail(MAGNET_E_DIM, "magnet_gaussian_update_cl: bad dims");
+    hipError_t e = magnet::launch_gaussian_update_cl(gnet_out_pad, ld, gmm_in, gmm_out, B, h, w, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_gaussian_update_cl launch");
+}
+
+MAGNET_API int magnet_upsample_depth_cl(const float* depth, const float* mask_pad, int32_t ld, float* out, int32_t B,
+                                        int32_t h, int32_t w, void* stream) {
+    if (!depth || !mask_pad || !out) return fail(MAGNET_E_NULL, "magnet_upsample_depth_cl: NULL pointer");
+    if (B <= 0 || h <= 0 || w <= 0 || ld < 144 || (ld % 4)) return fail(MAGNET_E_DIM, "magnet_upsample_depth_cl: bad dims (ld >= 144, ld %% 4 == 0)");
+    if (!aligned16(out) || !aligned16(mask_pad)) return fail(MAGNET_E_ALIGN, "magnet_upsample_depth_cl: pointers not 16-byte aligned");
+    hipError_t e = magnet::launch_upsample_cl(depth, mask_pad, ld, out, B, h, w, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_upsample_depth_cl launch");
 }
 
 }  // extern "C"

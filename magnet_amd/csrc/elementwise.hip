@@ -128,6 +128,75 @@ hipError_t launch_gaussian_update(const float* o, const float* g, float* out, in
     return hipGetLastError();
 }
 
+// gaussian update reading the conv kernel's padded channel-last fp32 output (B, h+2, w+2, ld)
+__global__ __launch_bounds__(256) void gaussian_update_cl_kernel(const float* __restrict__ o, int ld,
+                                                                  const float* __restrict__ g, float* __restrict__ out,
+                                                                  int B, int h, int w) {
+    const size_t hw = (size_t)h * w;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * hw) return;
+    const size_t b = i / hw, pp = i % hw;
+    const int y = (int)(pp / w), x = (int)(pp % w);
+    const float2 ov = *reinterpret_cast<const float2*>(o + (((size_t)b * (h + 2) + (y + 1)) * (w + 2) + (x + 1)) * ld);
+    const float mu0 = g[(b * 2 + 0) * hw + pp], sg0 = g[(b * 2 + 1) * hw + pp];
+    const float mu1 = mu0 + (ov.x * sg0);
+    const float e = (ov.y > 0.f) ? ov.y : expm1f(ov.y);
+    out[(b * 2 + 0) * hw + pp] = mu1;
+    out[(b * 2 + 1) * hw + pp] = ((e + 1.0f) + 1e-10f) * sg0;
+}
+
+hipError_t launch_gaussian_update_cl(const float* o, int ld, const float* g, float* out, int B, int h, int w, hipStream_t s) {
+    const size_t n = (size_t)B * h * w;
+    hipLaunchKernelGGL(gaussian_update_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, o, ld, g, out, B, h, w);
+    return hipGetLastError();
+}
+
+// convex x4 upsampling with the mask in padded channel-last fp32 (B, h+2, w+2, ld): thread = (pixel, sub-row i);
+// the 4 sub-columns j of one neighbour n are 16 contiguous bytes (channel n*16 + i*4 + j, MAGNET.py:19)
+__global__ __launch_bounds__(256) void upsample_cl_kernel(const float* __restrict__ depth, const float* __restrict__ mask,
+                                                           int ld, float* __restrict__ out, int B, int h, int w) {
+    const size_t hw = (size_t)h * w;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)B * hw * 4) return;
+    const int i = (int)(t & 3);
+    const size_t pi = t >> 2, b = pi / hw, pp = pi % hw;
+    const int y = (int)(pp / w), x = (int)(pp % w);
+    const float* m = mask + (((size_t)b * (h + 2) + (y + 1)) * (w + 2) + (x + 1)) * ld + i * 4;
+    float4 mv[9];
+    float4 mx = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        mv[n] = *reinterpret_cast<const float4*>(m + n * 16);
+        mx.x = fmaxf(mx.x, mv[n].x); mx.y = fmaxf(mx.y, mv[n].y); mx.z = fmaxf(mx.z, mv[n].z); mx.w = fmaxf(mx.w, mv[n].w);
+    }
+    float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        mv[n].x = __expf(mv[n].x - mx.x); mv[n].y = __expf(mv[n].y - mx.y);
+        mv[n].z = __expf(mv[n].z - mx.z); mv[n].w = __expf(mv[n].w - mx.w);
+        den.x += mv[n].x; den.y += mv[n].y; den.z += mv[n].z; den.w += mv[n].w;
+    }
+    const float4 inv = make_float4(1.0f / den.x, 1.0f / den.y, 1.0f / den.z, 1.0f / den.w);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int n = 0; n < 9; ++n) {
+            const int yy = y + n / 3 - 1, xx = x + n % 3 - 1;
+            const float dv = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? depth[((size_t)b * 2 + c) * hw + (size_t)yy * w + xx] : 0.f;
+            a.x += (mv[n].x * inv.x) * dv; a.y += (mv[n].y * inv.y) * dv;
+            a.z += (mv[n].z * inv.z) * dv; a.w += (mv[n].w * inv.w) * dv;
+        }
+        *reinterpret_cast<float4*>(out + (((size_t)b * 2 + c) * h * 4 + (size_t)y * 4 + i) * ((size_t)w * 4) + (size_t)x * 4) = a;
+    }
+}
+
+hipError_t launch_upsample_cl(const float* d, const float* m, int ld, float* o, int B, int h, int w, hipStream_t s) {
+    const size_t n = (size_t)B * h * w * 4;
+    hipLaunchKernelGGL(upsample_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, m, ld, o, B, h, w);
+    return hipGetLastError();
+}
+
 // ---- learned convex upsampling -------------------------------------------------------------------
 // One thread per coarse pixel; lanes run along x so every mask-plane read is coalesced; the k
 // sub-pixels of one output row are stored as one contiguous run per lane (16 B for k = 4).

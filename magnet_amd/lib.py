@@ -238,3 +238,98 @@ def upsample_depth(depth, up_mask, k: int, out=None):
         _check(load().magnet_upsample_depth(d.data_ptr(), m.data_ptr(), _dev(out, "out", torch.float32).data_ptr(),
                                             B, C, h, w, k, _stream(d)), "magnet_upsample_depth")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# G-Net / mask-head convolutions on the matrix cores (include/magnet_hip.h: magnet_conv_mfma & friends)
+# ---------------------------------------------------------------------------------------------------
+class MagnetConvArgs(ctypes.Structure):
+    """Mirror of `struct MagnetConvArgs` (include/magnet_hip.h)."""
+    _fields_ = [
+        ("in_hi", ctypes.c_void_p), ("in_lo", ctypes.c_void_p), ("w_hi", ctypes.c_void_p), ("w_lo", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p), ("out_hi", ctypes.c_void_p), ("out_lo", ctypes.c_void_p), ("out_f32", ctypes.c_void_p),
+        ("rows", ctypes.c_int64),
+        ("cin", ctypes.c_int32), ("cout_pad", ctypes.c_int32), ("taps", ctypes.c_int32), ("wp", ctypes.c_int32),
+        ("relu", ctypes.c_int32), ("out_mode", ctypes.c_int32), ("in_ld", ctypes.c_int32),
+    ]
+
+
+API_SYMBOLS = API_SYMBOLS + ("magnet_conv_mfma", "magnet_pack_split", "magnet_gaussian_update_cl",
+                             "magnet_upsample_depth_cl")
+
+
+def _conv_protos(lib):
+    if getattr(lib, "_conv_protos_done", False):
+        return lib
+    I, P = ctypes.c_int32, ctypes.c_void_p
+    lib.magnet_conv_mfma.restype = ctypes.c_int
+    lib.magnet_conv_mfma.argtypes = [ctypes.POINTER(MagnetConvArgs), P]
+    lib.magnet_pack_split.restype = ctypes.c_int
+    lib.magnet_pack_split.argtypes = [P, P, P, I, I, I, I, I, I, ctypes.c_int64, P]
+    lib.magnet_gaussian_update_cl.restype = ctypes.c_int
+    lib.magnet_gaussian_update_cl.argtypes = [P, I, P, P, I, I, I, P]
+    lib.magnet_upsample_depth_cl.restype = ctypes.c_int
+    lib.magnet_upsample_depth_cl.argtypes = [P, P, I, P, I, I, I, P]
+    lib._conv_protos_done = True
+    return lib
+
+
+def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, out_hi=None, out_lo=None, out_f32=None):
+    """One convolution layer on the matrix cores.  in_hi/in_lo: bf16 tensors whose data_ptr is row 0 (possibly a
+    channel-offset view of a wider buffer, `in_ld` = its row pitch in elements); weights (taps, cout_pad, cin) bf16."""
+    lib = _conv_protos(load())
+    a = MagnetConvArgs()
+    for t, n in ((in_hi, "in_hi"), (in_lo, "in_lo"), (w_hi, "w_hi"), (w_lo, "w_lo")):
+        if not t.is_cuda or t.dtype != torch.bfloat16:
+            raise MagnetError(f"conv_mfma: {n} must be a bf16 GPU tensor")
+    a.in_hi, a.in_lo, a.w_hi, a.w_lo = in_hi.data_ptr(), in_lo.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr()
+    a.bias = _dev(bias, "bias", torch.float32).data_ptr()
+    a.rows, a.cin, a.cout_pad, a.taps, a.wp = int(rows), int(cin), int(w_hi.shape[1]), int(taps), int(wp)
+    a.relu, a.in_ld = int(bool(relu)), int(in_ld)
+    if out_f32 is not None:
+        a.out_mode, a.out_f32 = 1, _dev(out_f32, "out_f32", torch.float32).data_ptr()
+    else:
+        a.out_mode, a.out_hi, a.out_lo = 0, _dev(out_hi, "out_hi", torch.bfloat16).data_ptr(), \
+            _dev(out_lo, "out_lo", torch.bfloat16).data_ptr()
+    with torch.cuda.device(in_hi.device):
+        _check(lib.magnet_conv_mfma(ctypes.byref(a), _stream(in_hi)), "magnet_conv_mfma")
+
+
+def pack_split(x_nchw, out_hi, out_lo, ctot, c_off):
+    """fp32 (N,C,h,w) (dense, or a leading-channel slice of a wider NCHW tensor) -> interior of the split-bf16
+    padded channel-last buffer (N,h+2,w+2,ctot), channels [c_off, c_off+C)."""
+    lib = _conv_protos(load())
+    if not x_nchw.is_cuda or x_nchw.dtype != torch.float32:
+        raise MagnetError("pack_split: input must be a float32 GPU tensor")
+    N, C, h, w = x_nchw.shape
+    if x_nchw.stride()[1:] != (h * w, w, 1):
+        raise MagnetError(f"pack_split: unsupported input strides {x_nchw.stride()}")
+    with torch.cuda.device(x_nchw.device):
+        _check(lib.magnet_pack_split(x_nchw.data_ptr(), out_hi.data_ptr(), out_lo.data_ptr(), N, C, h, w, int(ctot),
+                                     int(c_off), int(x_nchw.stride(0)) if N > 1 else 0, _stream(x_nchw)), "magnet_pack_split")
+
+
+def gaussian_update_cl(gnet_out_pad, ld, gmm_in, h, w, out=None):
+    lib = _conv_protos(load())
+    g = _dev(gmm_in, "gmm_in", torch.float32)
+    if out is None:
+        out = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        _check(lib.magnet_gaussian_update_cl(_dev(gnet_out_pad, "gnet_out_pad", torch.float32).data_ptr(), int(ld),
+                                             g.data_ptr(), out.data_ptr(), g.shape[0], h, w, _stream(g)),
+               "magnet_gaussian_update_cl")
+    return out
+
+
+def upsample_depth_cl(depth, mask_pad, ld, out=None):
+    lib = _conv_protos(load())
+    d = _dev(depth, "depth", torch.float32)
+    B, C, h, w = d.shape
+    if C != 2:
+        raise MagnetError("upsample_depth_cl: depth must be (B,2,h,w)")
+    if out is None:
+        out = torch.empty((B, 2, 4 * h, 4 * w), dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device):
+        _check(lib.magnet_upsample_depth_cl(d.data_ptr(), _dev(mask_pad, "mask_pad", torch.float32).data_ptr(), int(ld),
+                                            out.data_ptr(), B, h, w, _stream(d)), "magnet_upsample_depth_cl")
+    return out

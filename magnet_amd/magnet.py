@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import lib
+from .convnet import ConvStackMFMA
 from .homography import CostVolumeCW
 
 
@@ -80,10 +81,12 @@ class MAGNET(nn.Module):
     backbones are out of this build's scope: pass them as `d_net` (img -> ((N,2,h,w), (N,256,h,w))) and
     `f_net` (img -> (N,F,h,w)); if omitted, the reference's own `models.DNET.DNET` / `models.FNET.FNET`
     are imported when the caller has them on sys.path (they need torch.hub / checkpoints).
-    `feat_dtype`: 'fp32' or 'bf16' storage of F-Net features inside the matcher."""
+    `feat_dtype`: 'fp32' or 'bf16' storage of F-Net features inside the matcher.
+    `conv_backend`: 'mfma' runs g_net / mask_head on the bf16x3 matrix-core kernel at inference (csrc/conv_mfma.hip,
+    fp32-grade); 'torch' keeps them on nn.Conv2d (MIOpen).  Autograd always takes the torch path."""
 
     def __init__(self, args, d_net: nn.Module | None = None, f_net: nn.Module | None = None,
-                 feat_dtype: str = "fp32"):
+                 feat_dtype: str = "fp32", conv_backend: str = "mfma"):
         super().__init__()
         self.args = args
         if d_net is None or f_net is None:
@@ -119,7 +122,12 @@ class MAGNET(nn.Module):
         self.k_list = self.depth_sampling()
         self.downsample_ratio = args.downsample_ratio
         self.feat_dtype = feat_dtype
-        self.matcher_path = 0          # 0 auto / 1 generic / 2 window kernel (include/magnet_hip.h `path`)
+        self.matcher_path = 0          # kernel selection of the matcher (include/magnet_hip.h `path`)
+        if conv_backend not in ("mfma", "torch"):
+            raise lib.MagnetError(f"conv_backend must be 'mfma' or 'torch', got {conv_backend!r}")
+        self.conv_backend = conv_backend
+        self._work = {}                # cached device workspaces of the MFMA conv path, keyed by shape
+        self._stacks = None
 
         dnet_fdim = 256
         self.g_net = GNET(ch_in=dnet_fdim + self.n_samples, ch_out=2)
@@ -143,11 +151,16 @@ class MAGNET(nn.Module):
                                thres, feat_dtype=self.feat_dtype, path=self.matcher_path)
         B, _, h, w = ref_gmms.shape
         n_iter = self.train_iter if mode == "train" else self.test_iter
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in
+                                                   list(self.g_net.parameters()) + list(self.mask_head.parameters()))
+        if self.conv_backend == "mfma" and not training and self.downsample_ratio == 4 and x_d3.shape[1] == 256:
+            return self._refine_mfma(matcher, ref_gmms, x_d3, n_iter)
+
+        # ---- torch (MIOpen) convolutions: training, or conv_backend='torch' ----
         # G-Net input buffer: cost volume first, then x_d3 (MAGNET.py:167); x_d3 is copied once
         gnet_in = torch.empty((B, self.n_samples + x_d3.shape[1], h, w), dtype=torch.float32, device=x_d3.device)
         gnet_in[:, self.n_samples:] = x_d3
         cost_view = gnet_in[:, :self.n_samples]          # the kernel writes here directly (strided frames)
-        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.g_net.parameters())
         pred_list = [ref_gmms]
         for _ in range(n_iter):
             matcher(ref_gmm=pred_list[-1].detach(), k_list=self.k_list, out=cost_view)  # MAGNET.py:153-164
@@ -158,6 +171,40 @@ class MAGNET(nn.Module):
             pred_list.append(new_pred)
         mask = self.mask_head(x_d3)                                                       # MAGNET.py:172
         return [self.upsample_depth(pred, mask, self.downsample_ratio) for pred in pred_list[1:]]
+
+    def _refine_mfma(self, matcher, ref_gmms, x_d3, n_iter):
+        """Inference loop with g_net / mask_head on the matrix cores.  One zero-bordered channel-last buffer
+        (B, h+2, w+2, Ctot) in split-bf16 holds [cost (D, padded to 8) | x_d3 (256)]: x_d3 is packed once and is
+        read in place by the mask head (channel offset) and by every G-Net iteration; only the D cost channels
+        are re-packed per iteration (replaces torch.cat, MAGNET.py:167)."""
+        B, _, h, w = ref_gmms.shape
+        D = self.n_samples
+        Dp = (D + 7) // 8 * 8
+        dev = x_d3.device
+        if self._stacks is None:
+            self._stacks = (ConvStackMFMA(self.g_net.gnet, in_map=[(0, D, 0), (D, 256, Dp)]),
+                            ConvStackMFMA(self.mask_head))
+        g_stack, m_stack = self._stacks
+        ctot = g_stack.cin_pad()
+        rows, wp = B * (h + 2) * (w + 2), w + 2
+        wkey = (str(dev), B, h, w, ctot)
+        work = self._work.get(wkey)
+        if work is None:
+            self._work.clear()                       # one shape at a time: the buffers are large
+            work = self._work[wkey] = {
+                "gin": (torch.zeros((rows, ctot), dtype=torch.bfloat16, device=dev),      # zero border / zero pad
+                        torch.zeros((rows, ctot), dtype=torch.bfloat16, device=dev)),     # channels stay zero
+                "cost": torch.empty((B, D, h, w), dtype=torch.float32, device=dev)}
+        gin_hi, gin_lo = work["gin"]
+        lib.pack_split(x_d3.detach().float().contiguous(), gin_hi, gin_lo, ctot, Dp)
+        mask_pad, mask_ld = m_stack.run(gin_hi[:, Dp:], gin_lo[:, Dp:], ctot, rows, wp, work)       # MAGNET.py:172
+        pred_list = [ref_gmms.detach().float().contiguous()]
+        for _ in range(n_iter):
+            matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out=work["cost"])                    # MAGNET.py:153-164
+            lib.pack_split(work["cost"], gin_hi, gin_lo, ctot, 0)
+            g_out, g_ld = g_stack.run(gin_hi, gin_lo, ctot, rows, wp, work)                          # MAGNET.py:62
+            pred_list.append(lib.gaussian_update_cl(g_out, g_ld, pred_list[-1], h, w))               # MAGNET.py:60-69
+        return [lib.upsample_depth_cl(pred, mask_pad, mask_ld) for pred in pred_list[1:]]            # MAGNET.py:173
 
     def forward(self, ref_img, nghbr_imgs, nghbr_poses, is_valid, cam_intrins, mode="train"):
         B = ref_img.shape[0]

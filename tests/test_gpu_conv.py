@@ -1,0 +1,95 @@
+"""-m gpu: the bf16x3 MFMA convolution path against torch fp32 convolutions on the CPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _stack(cin, cout_last, seed):
+    torch.manual_seed(seed)
+    seq = nn.Sequential(nn.Conv2d(cin, 128, 3, padding=1), nn.ReLU(inplace=True),
+                        nn.Conv2d(128, 128, 1), nn.ReLU(inplace=True),
+                        nn.Conv2d(128, 128, 1), nn.ReLU(inplace=True),
+                        nn.Conv2d(128, cout_last, 1))
+    return seq.eval()
+
+
+def _run_stack(seq, x, gpu, in_map=None):
+    """x: (B, C, h, w) fp32 CPU -> interior of the stack's fp32 output, (B, cout, h, w)."""
+    from magnet_amd import lib
+    from magnet_amd.convnet import ConvStackMFMA
+    B, C, h, w = x.shape
+    st = ConvStackMFMA(seq.to(gpu), in_map=in_map)
+    ctot = st.cin_pad()
+    rows = B * (h + 2) * (w + 2)
+    hi = torch.zeros((rows, ctot), dtype=torch.bfloat16, device=gpu); lo = torch.zeros_like(hi)
+    if in_map is None:
+        lib.pack_split(x.to(gpu), hi, lo, ctot, 0)
+    else:
+        for src, n, dst in in_map:
+            lib.pack_split(x[:, src:src + n].contiguous().to(gpu), hi, lo, ctot, dst)
+    out, ld = st.run(hi, lo, ctot, rows, w + 2, {})
+    cout = seq[-1].out_channels
+    o = out.view(B, h + 2, w + 2, ld)[:, 1:-1, 1:-1, :cout].permute(0, 3, 1, 2).contiguous().cpu()
+    seq.cpu()
+    return o
+
+
+@pytest.mark.parametrize("cin,cout,h,w,B", [(320, 2, 12, 16, 2), (256, 144, 9, 21, 1), (64, 2, 30, 40, 3)])
+def test_conv_stack_matches_fp32(hip_lib, gpu, cin, cout, h, w, B):
+    seq = _stack(cin, cout, seed=cin + cout)
+    x = torch.randn(B, cin, h, w, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        ref = seq(x)
+    got = _run_stack(seq, x, gpu)
+    err = (got - ref).abs().max().item(); scale = ref.abs().max().item()
+    print(f"[conv {cin}->{cout}] max|d|={err:.3e} max|ref|={scale:.3f} rel={err / scale:.2e}")
+    assert torch.isfinite(got).all() and err <= 2e-5 * max(1.0, scale)
+
+
+def test_conv_stack_channel_map_odd_D(hip_lib, gpu):
+    """G-Net with D = 5: cost channels [0,5), x_d3 at channel offset 8 of the 288-wide buffer."""
+    seq = _stack(256 + 5, 2, seed=3)
+    x = torch.randn(2, 261, 12, 16, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        ref = seq(x)
+    got = _run_stack(seq, x, gpu, in_map=[(0, 5, 0), (5, 256, 8)])
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_single_layer_asymmetric(hip_lib, gpu):
+    """One 3x3 layer with a one-hot weight: a transposed operand or a wrong tap offset cannot pass."""
+    from magnet_amd import lib
+    from magnet_amd.convnet import ConvStackMFMA
+    conv = nn.Conv2d(32, 128, 3, padding=1, bias=False)
+    with torch.no_grad():
+        conv.weight.zero_()
+        conv.weight[7, 3, 0, 2] = 1.0           # out ch 7 <- in ch 3 at (dy=-1, dx=+1)
+        conv.weight[100, 31, 2, 1] = -2.0       # out ch 100 <- in ch 31 at (dy=+1, dx=0)
+    seq = nn.Sequential(conv).eval()
+    x = torch.randn(1, 32, 10, 14, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        ref = seq(x)
+    got = _run_stack(seq, x, gpu)
+    assert torch.allclose(got, ref, atol=1e-6)
+    assert got[0, 7].abs().sum() > 0 and got[0, 8].abs().sum() == 0
+
+
+def test_gaussian_update_and_upsample_cl(hip_lib, gpu):
+    from magnet_amd import lib
+    from oracle import oracle
+    g = torch.Generator().manual_seed(9)
+    B, h, w = 2, 7, 11
+    o = torch.randn(B, 2, h, w, generator=g) * 2; gmm = torch.rand(B, 2, h, w, generator=g) + 0.2
+    pad = torch.full((B, h + 2, w + 2, 16), 3.0)
+    pad[:, 1:-1, 1:-1, :2] = o.permute(0, 2, 3, 1)
+    got = lib.gaussian_update_cl(pad.to(gpu).view(-1, 16), 16, gmm.to(gpu), h, w).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.gaussian_update(o.numpy(), gmm.numpy()), rtol=1e-6, atol=1e-6)
+    m = torch.randn(B, 144, h, w, generator=g) * 2; d = torch.rand(B, 2, h, w, generator=g) * 4
+    mp = torch.full((B, h + 2, w + 2, 144), -5.0)
+    mp[:, 1:-1, 1:-1] = m.permute(0, 2, 3, 1)
+    got = lib.upsample_depth_cl(d.to(gpu), mp.to(gpu).view(-1, 144), 144).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.upsample_depth_via_mask(d.numpy(), m.numpy(), 4), rtol=0, atol=5e-6)

@@ -231,12 +231,13 @@ def test_upsample(hip_lib, gpu, golden, k):
 
 
 # ---- full loop ----------------------------------------------------------------------------------------------
-def test_magnet_forward_matches_reference_output(hip_lib, gpu, golden):
+@pytest.mark.parametrize("backend", ["mfma", "torch"])
+def test_magnet_forward_matches_reference_output(hip_lib, gpu, golden, backend):
     """G6: the reference's MAGNET.forward output (stub D-Net/F-Net, I=3, one invalid view) vs ours:
     final-depth abs_rel delta < 1e-4 (BASELINE.json's parity bar)."""
     from magnet_amd.magnet import MAGNET
     args = make_args(D=5, iters=3, dpv_h=12, dpv_w=16)
-    m = MAGNET(args, d_net=StubDNet(seed=21), f_net=StubFNet(seed=22, fdim=8))
+    m = MAGNET(args, d_net=StubDNet(seed=21), f_net=StubFNet(seed=22, fdim=8), conv_backend=backend)
     seeded_magnet_weights(m, seed=23)
     m = m.to(gpu).eval()
     intr = synth.make_intrinsics("scannet", 12, 16, 2)
@@ -254,14 +255,15 @@ def test_magnet_forward_matches_reference_output(hip_lib, gpu, golden):
         np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=5e-3, atol=1e-6)
 
 
-def test_full_loop_abs_rel_C3_shape(hip_lib, gpu):
+@pytest.mark.parametrize("backend", ["mfma", "torch"])
+def test_full_loop_abs_rel_C3_shape(hip_lib, gpu, backend):
     """C3 shape (120x160, V=4, D=64, I=3, bf16 storage): HIP loop vs an oracle loop (oracle matcher +
     torch-CPU G-Net + oracle tail/upsample) on identical inputs: abs_rel delta < 1e-4."""
     from magnet_amd.magnet import MAGNET
     wl = synth.WORKLOADS["C3"]
     inp = synth.make_inputs(wl, B=1, seed=0)
     args = make_args(D=wl.D, iters=3, dpv_h=wl.h, dpv_w=wl.w)
-    m = MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2), feat_dtype="bf16")
+    m = MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2), feat_dtype="bf16", conv_backend=backend)
     seeded_magnet_weights(m, seed=5)
     x_d3 = torch.randn(1, 256, wl.h, wl.w, generator=torch.Generator().manual_seed(7)) * 0.5
     # oracle loop on the CPU
