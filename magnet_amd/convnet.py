@@ -35,6 +35,10 @@ class ConvStackMFMA:
     """`seq`: nn.Sequential of Conv2d / ReLU as in the reference.  `in_map`: how the first layer's input channels are
     laid out in the (wider, 32-aligned) input buffer: list of (src_start, length, dst_start)."""
 
+    # When set to a list, every layer launch appends (start_event, end_event, flops, taps) recorded on the launch
+    # stream (bench.py's live timing of the convolution kernel).
+    event_sink = None
+
     def __init__(self, seq: nn.Sequential, in_map=None):
         self.layers = []
         mods = list(seq)
@@ -99,12 +103,19 @@ class ConvStackMFMA:
         cur_hi, cur_lo, cur_ld = in_hi, in_lo, in_ld
         for li, pk in enumerate(packs):
             last = li == len(packs) - 1
+            sink = ConvStackMFMA.event_sink
+            if sink is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                sink.append((e0, e1, 2.0 * rows * pk["cout_pad"] * pk["cin"] * pk["taps"], pk["taps"]))
             if last:
                 key = ("out", rows, pk["cout_pad"])
                 if key not in work:
                     work[key] = torch.empty((rows, pk["cout_pad"]), dtype=torch.float32, device=in_hi.device)
                 lib.conv_mfma(cur_hi, cur_lo, cur_ld, pk["cin"], pk["w_hi"], pk["w_lo"], pk["bias"], pk["taps"], wp,
                               pk["relu"], rows, out_f32=work[key])
+                if sink is not None:
+                    e1.record()
                 return work[key], pk["cout_pad"]
             key = ("hid", li & 1, rows, pk["cout_pad"])
             if key not in work:
@@ -113,4 +124,6 @@ class ConvStackMFMA:
             oh, ol = work[key]
             lib.conv_mfma(cur_hi, cur_lo, cur_ld, pk["cin"], pk["w_hi"], pk["w_lo"], pk["bias"], pk["taps"], wp,
                           pk["relu"], rows, out_hi=oh, out_lo=ol)
+            if sink is not None:
+                e1.record()
             cur_hi, cur_lo, cur_ld = oh, ol, pk["cout_pad"]
