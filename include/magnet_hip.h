@@ -134,6 +134,13 @@ typedef struct MagnetConvArgs {
 
 MAGNET_API int magnet_conv_mfma(const MagnetConvArgs *args, void *stream);
 
+/* The 1x1 tail of a stack in one launch: relu(conv1x1 128->128), relu(conv1x1 128->128), conv1x1 128->cout_pad.
+ * in: split-bf16 (rows,128) planes (the 3x3 layer's out_mode-0 output); w_hi/w_lo: the three layers' [cout][128]
+ * bf16 planes concatenated; bias: 128 + 128 + cout_pad floats; out: fp32 (rows, cout_pad).  cout_pad in {16,128,144}.
+ * (models/MAGNET.py:53-55 and :113-115.) */
+MAGNET_API int magnet_conv1x1_chain(const void *in_hi, const void *in_lo, const void *w_hi, const void *w_lo,
+                                    const float *bias, float *out, int64_t rows, int32_t cout_pad, void *stream);
+
 /* fp32 NCHW (N, C, h, w) (image stride `in_img_stride` elements, 0 = C*h*w) -> the interior of the split-bf16
  * padded channel-last buffer (N, h+2, w+2, ctot), channels [c_off, c_off+round_up(C,8)) (the round-up lanes are
  * written as zeros).  c_off % 8 == 0.  The border must have been zeroed once by the caller (never written). */

@@ -55,6 +55,12 @@ class ConvStackMFMA:
             self.layers.append((conv, relu))
             i += 2 if relu else 1
         self.in_map = in_map
+        # Fused 1x1-chain kernel (magnet_conv1x1_chain): bit-identical results, but MEASURED SLOWER on MI355X
+        # (1.41 + 1.04 ms vs 0.94 + 0.79 ms per 64-frame step for the two stacks): its 101 KB LDS tile allows one
+        # workgroup per CU, so its load phase is not overlapped, whereas the separate launches are HBM-bound at
+        # high occupancy.  Off by default; kept (and tested) as the starting point for a 64-row-tile variant.
+        self.fuse_tail = False
+        self._chain = None
         self._packed = None
         self._key = None
 
@@ -93,6 +99,15 @@ class ConvStackMFMA:
             cin_p = cp                                                                 # next layer reads all padded channels
             if li + 1 < len(self.layers) and cp % 32 != 0:
                 raise lib.MagnetError("hidden layer width must be a multiple of 32")
+        # the reference's stacks end in 1x1(128->128)+ReLU, 1x1(128->128)+ReLU, 1x1(128->cout): fused into one launch
+        self._chain = None
+        if len(out) == 4 and all(o["taps"] == 1 for o in out[1:]) and out[1]["relu"] and out[2]["relu"] and \
+                not out[3]["relu"] and out[0]["cout_pad"] == 128 and out[1]["cout_pad"] == 128 and \
+                out[2]["cout_pad"] == 128 and out[3]["cout_pad"] in (16, 128, 144) and out[0]["relu"]:
+            self._chain = dict(
+                w_hi=torch.cat([o["w_hi"].reshape(-1) for o in out[1:]]).contiguous(),
+                w_lo=torch.cat([o["w_lo"].reshape(-1) for o in out[1:]]).contiguous(),
+                bias=torch.cat([o["bias"] for o in out[1:]]).contiguous(), cout_pad=out[3]["cout_pad"])
         self._packed, self._key = out, key
         return out
 
@@ -101,6 +116,34 @@ class ConvStackMFMA:
         hidden buffers.  Returns (fp32 tensor (rows, cout_pad_last), cout_pad_last)."""
         packs = self.packed(in_hi.device)
         cur_hi, cur_lo, cur_ld = in_hi, in_lo, in_ld
+        if self._chain is not None and self.fuse_tail:
+            pk = packs[0]
+            key = ("hid", 0, rows, 128)
+            if key not in work:
+                work[key] = (torch.empty((rows, 128), dtype=torch.bfloat16, device=in_hi.device),
+                             torch.empty((rows, 128), dtype=torch.bfloat16, device=in_hi.device))
+            oh, ol = work[key]
+            sink = ConvStackMFMA.event_sink
+            if sink is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                sink.append((e0, e1, 2.0 * rows * pk["cout_pad"] * pk["cin"] * pk["taps"], pk["taps"]))
+            lib.conv_mfma(cur_hi, cur_lo, cur_ld, pk["cin"], pk["w_hi"], pk["w_lo"], pk["bias"], pk["taps"], wp,
+                          pk["relu"], rows, out_hi=oh, out_lo=ol)
+            if sink is not None:
+                e1.record()
+            ch = self._chain
+            key = ("out", rows, ch["cout_pad"])
+            if key not in work:
+                work[key] = torch.empty((rows, ch["cout_pad"]), dtype=torch.float32, device=in_hi.device)
+            if sink is not None:
+                c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
+                c0.record()
+                sink.append((c0, c1, 2.0 * rows * 128 * (256 + ch["cout_pad"]), 1))
+            lib.conv1x1_chain(oh, ol, ch["w_hi"], ch["w_lo"], ch["bias"], work[key], rows, ch["cout_pad"])
+            if sink is not None:
+                c1.record()
+            return work[key], ch["cout_pad"]
         for li, pk in enumerate(packs):
             last = li == len(packs) - 1
             sink = ConvStackMFMA.event_sink

@@ -22,6 +22,15 @@ struct ConvParams {
     int in_ld;
 };
 hipError_t launch_conv_mfma(const ConvParams&, hipStream_t);
+struct ChainParams {
+    const uint16_t* in_hi;  const uint16_t* in_lo;
+    const uint16_t* w_hi;   const uint16_t* w_lo;
+    const float*    bias;
+    float*          out;
+    long long rows;
+    int cout_pad;
+};
+hipError_t launch_conv1x1_chain(const ChainParams&, hipStream_t);
 hipError_t launch_pack_split(const float*, uint16_t*, uint16_t*, int, int, int, int, int, int, long long, hipStream_t);
 hipError_t launch_gaussian_update_cl(const float*, int, const float*, float*, int, int, int, hipStream_t);
 hipError_t launch_upsample_cl(const float*, const float*, int, float*, int, int, int, hipStream_t);
@@ -182,6 +191,20 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     if (p.in_ld < a->cin || (p.in_ld % 8) != 0) return fail(MAGNET_E_DIM, "magnet_conv_mfma: in_ld=%d must be >= cin and a multiple of 8", p.in_ld);
     hipError_t e = magnet::launch_conv_mfma(p, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_conv_mfma launch");
+}
+
+MAGNET_API int magnet_conv1x1_chain(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias,
+                                    float* out, int64_t rows, int32_t cout_pad, void* stream) {
+    if (!in_hi || !in_lo || !w_hi || !w_lo || !bias || !out) return fail(MAGNET_E_NULL, "magnet_conv1x1_chain: NULL pointer");
+    if (rows <= 0 || (cout_pad != 16 && cout_pad != 144 && cout_pad != 128))
+        return fail(MAGNET_E_DIM, "magnet_conv1x1_chain: rows > 0 and cout_pad in {16, 128, 144} required (got %d)", cout_pad);
+    if (!aligned16(in_hi) || !aligned16(in_lo) || !aligned16(w_hi) || !aligned16(w_lo) || !aligned16(out) || !aligned16(bias))
+        return fail(MAGNET_E_ALIGN, "magnet_conv1x1_chain: pointers must be 16-byte aligned");
+    magnet::ChainParams p;
+    p.in_hi = (const uint16_t*)in_hi; p.in_lo = (const uint16_t*)in_lo; p.w_hi = (const uint16_t*)w_hi; p.w_lo = (const uint16_t*)w_lo;
+    p.bias = bias; p.out = out; p.rows = rows; p.cout_pad = cout_pad;
+    hipError_t e = magnet::launch_conv1x1_chain(p, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_conv1x1_chain launch");
 }
 
 MAGNET_API int magnet_pack_split(const float* nchw, void* out_hi, void* out_lo, int32_t N, int32_t C, int32_t h, int32_t w,

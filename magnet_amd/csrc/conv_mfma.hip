@@ -15,10 +15,11 @@
 //         120x160) and hold garbage that no interior output ever reads; callers read interior rows only.
 //   act = two bf16 planes (hi, lo), W = two bf16 planes of [tap][Cout_pad][Cin] (Cin contiguous), so both
 //         MFMA operands are "row-major with K contiguous": one 16-byte LDS read per fragment per lane.
-// Tiling: workgroup = 128 rows x BN = NF*16 output channels, 4 waves stacked along M (32 rows each, all
-// channels), K step 32; global -> registers -> LDS staging with the next step's loads in flight during the
-// MFMAs; LDS rows padded to 80 B (conflict-free ds_read_b128); epilogue through LDS: bias, ReLU, then
-// either re-split to bf16 hi/lo planes (input of the next layer) or fp32 rows (last layer).
+// Tiling: workgroup = 128 rows x BN = NF*16 output channels, 2x2 waves of 64x64 (BN = 128) or 4 waves stacked
+// along M (BN = 144, 16), K step 32; global -> registers -> LDS staging with the next step's loads in flight during the
+// MFMAs into the other half of a double-buffered, XOR-swizzled (conflict-free) LDS image: one barrier per K
+// step; epilogue through LDS: bias, ReLU, then either re-split to bf16 hi/lo planes (input of the next layer)
+// or fp32 rows (last layer).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/magnet_hip.h"
@@ -39,8 +40,15 @@ struct ConvParams {
     int in_ld;                                        // elements between consecutive input rows (>= cin)
 };
 
-constexpr int CV_BM = 128, CV_BK = 32;
-constexpr int CV_LDS_ROW = 80;                        // bytes per staged row: 64 data + 16 pad
+constexpr int CV_BK = 32;
+constexpr int CV_ROW = 64;                            // bytes per staged row (32 bf16), unpadded
+
+// LDS image of a [rows][32 bf16] tile: 64-byte rows, the four 16-byte slots of a row XOR-swizzled with
+// ((row >> 1) & 3).  Conflict-free for both access patterns (checked against the ds_read_b128 /
+// ds_write_b128 lane groups of MI355X_MICROARCH.md §LDS): MFMA fragment reads (lane -> row = lane&15,
+// slot = lane>>4) and the staging writes (thread -> row = t>>2, slot = t&3).  The first version used
+// 80-byte padded rows: SQ_LDS_BANK_CONFLICT was 50 % of SQ_LDS_IDX_ACTIVE.
+__device__ __forceinline__ int cv_swz(int row, int slot) { return row * CV_ROW + ((slot ^ ((row >> 1) & 3)) << 4); }
 
 __device__ __forceinline__ uint16_t bf16_rne(float f) {
     uint32_t u = __float_as_uint(f);
@@ -53,33 +61,35 @@ __device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) 
     lo = bf16_rne(x - __uint_as_float((uint32_t)hi << 16));
 }
 
-// NF = 16-column fragments per wave = BN/16 (8: 128 channels, 9: 144, 1: 16)
-template <int NF>
+// NF = 16-column fragments of the workgroup tile (BN = NF*16: 128, 144 or 16 channels);
+// WN = waves along N (2: 2x2 waves; 1: 4x1 waves); CV_BM = rows of the workgroup tile (128 or 256)
+template <int NF, int WN, int CV_BM>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int BN = NF * 16;
-    constexpr int A_BYTES = CV_BM * CV_LDS_ROW, B_BYTES = BN * CV_LDS_ROW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* a_hi = smem;
-    unsigned char* a_lo = smem + A_BYTES;
-    unsigned char* b_hi = smem + 2 * A_BYTES;
-    unsigned char* b_lo = smem + 2 * A_BYTES + B_BYTES;
+    constexpr int A_PT = CV_BM / 64;                           // 16-byte vectors per thread per A plane (2 or 4)
+    constexpr int WM = 4 / WN;                        // waves along M
+    constexpr int MF = CV_BM / (WM * 16);             // M fragments per wave (2 or 4)
+    constexpr int NFW = NF / WN;                      // N fragments per wave
+    static_assert(NF % WN == 0, "N fragments must split evenly over the waves");
+    constexpr int A_BYTES = CV_BM * CV_ROW, B_BYTES = BN * CV_ROW;
+    constexpr int STAGE_BYTES = 2 * A_BYTES + 2 * B_BYTES;    // hi + lo planes of A and B
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two stages (double buffer)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
     const long long row0 = (long long)blockIdx.x * CV_BM;
     const int n0 = blockIdx.y * BN;
 
-    // staging roles: a 64-byte K-slice of one row = 4 x 16 B; thread -> (row, quarter)
-    constexpr int A_VEC = CV_BM * 4, B_VEC = BN * 4;          // 16-byte vectors per plane
-    constexpr int A_PT = A_VEC / 256;                          // = 2
-    constexpr int B_PT = (B_VEC + 255) / 256;                  // 2 (BN=128), 3 (BN=144), 1 (BN=16)
-    static_assert(A_PT == 2 && B_PT <= 3, "staging registers below are spelled out for these sizes");
+    // staging: a 64-byte K-slice of one row = 4 x 16 B; thread -> (row, quarter), +64 / +128 rows for more
+    constexpr int B_PT = (BN * 4 + 255) / 256;                 // 16-byte vectors per thread per B plane
+    static_assert(B_PT <= 3, "staging registers below are spelled out for these sizes");
     // explicit scalars: arrays here end up in scratch memory (the compiler does not promote them)
-    uint4 ah0, ah1, al0, al1, bh0, bh1, bh2, bl0, bl1, bl2;
-    bh1 = bh2 = bl1 = bl2 = make_uint4(0, 0, 0, 0);
+    uint4 ah0, ah1, ah2, ah3, al0, al1, al2, al3, bh0, bh1, bh2, bl0, bl1, bl2;
+    bh1 = bh2 = bl1 = bl2 = ah2 = ah3 = al2 = al3 = make_uint4(0, 0, 0, 0);
 
     const int ksteps_per_tap = p.cin / CV_BK;
     const int nsteps = p.taps * ksteps_per_tap;
-    const int st_r = tid >> 2, st_q = tid & 3;                 // staging role: row (+64, +128 for later vectors), quarter
+    const int st_r = tid >> 2, st_q = tid & 3;
 
     auto a_elem = [&](int s, int i) -> size_t {
         const int tap = s / ksteps_per_tap, k0 = (s % ksteps_per_tap) * CV_BK;
@@ -99,87 +109,104 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         const size_t ea0 = a_elem((S), 0), ea1 = a_elem((S), 1);                          \
         ah0 = CV_LD(p.in_hi, ea0); al0 = CV_LD(p.in_lo, ea0);                             \
         ah1 = CV_LD(p.in_hi, ea1); al1 = CV_LD(p.in_lo, ea1);                             \
+        if constexpr (A_PT == 4) {                                                        \
+            const size_t ea2 = a_elem((S), 2), ea3 = a_elem((S), 3);                      \
+            ah2 = CV_LD(p.in_hi, ea2); al2 = CV_LD(p.in_lo, ea2);                         \
+            ah3 = CV_LD(p.in_hi, ea3); al3 = CV_LD(p.in_lo, ea3);                         \
+        }                                                                                 \
         const size_t eb0 = b_elem((S), 0);                                                \
         bh0 = CV_LD(p.w_hi, eb0); bl0 = CV_LD(p.w_lo, eb0);                               \
         if constexpr (B_PT >= 2) { const size_t eb1 = b_elem((S), 1); bh1 = CV_LD(p.w_hi, eb1); bl1 = CV_LD(p.w_lo, eb1); } \
         if constexpr (B_PT >= 3) { const size_t eb2 = b_elem((S), 2); bh2 = CV_LD(p.w_hi, eb2); bl2 = CV_LD(p.w_lo, eb2); } \
     }
-#define CV_ST(base, r, v) (*reinterpret_cast<uint4*>((base) + (r) * CV_LDS_ROW + st_q * 16) = (v))
-#define CV_COMMIT()                                                                       \
+#define CV_ST(base, r, v) (*reinterpret_cast<uint4*>((base) + cv_swz((r), st_q)) = (v))
+#define CV_COMMIT(BUF)                                                                    \
     {                                                                                     \
-        CV_ST(a_hi, st_r, ah0); CV_ST(a_lo, st_r, al0);                                   \
-        CV_ST(a_hi, st_r + 64, ah1); CV_ST(a_lo, st_r + 64, al1);                         \
-        if (st_r < BN) { CV_ST(b_hi, st_r, bh0); CV_ST(b_lo, st_r, bl0); }                \
-        if constexpr (B_PT >= 2) if (st_r + 64 < BN) { CV_ST(b_hi, st_r + 64, bh1); CV_ST(b_lo, st_r + 64, bl1); }   \
-        if constexpr (B_PT >= 3) if (st_r + 128 < BN) { CV_ST(b_hi, st_r + 128, bh2); CV_ST(b_lo, st_r + 128, bl2); } \
+        unsigned char* sa_hi = smem + (BUF) * STAGE_BYTES;                                \
+        unsigned char* sa_lo = sa_hi + A_BYTES;                                           \
+        unsigned char* sb_hi = sa_hi + 2 * A_BYTES;                                       \
+        unsigned char* sb_lo = sb_hi + B_BYTES;                                           \
+        CV_ST(sa_hi, st_r, ah0); CV_ST(sa_lo, st_r, al0);                                 \
+        CV_ST(sa_hi, st_r + 64, ah1); CV_ST(sa_lo, st_r + 64, al1);                       \
+        if constexpr (A_PT == 4) {                                                        \
+            CV_ST(sa_hi, st_r + 128, ah2); CV_ST(sa_lo, st_r + 128, al2);                 \
+            CV_ST(sa_hi, st_r + 192, ah3); CV_ST(sa_lo, st_r + 192, al3);                 \
+        }                                                                                 \
+        if (st_r < BN) { CV_ST(sb_hi, st_r, bh0); CV_ST(sb_lo, st_r, bl0); }              \
+        if constexpr (B_PT >= 2) if (st_r + 64 < BN) { CV_ST(sb_hi, st_r + 64, bh1); CV_ST(sb_lo, st_r + 64, bl1); }   \
+        if constexpr (B_PT >= 3) if (st_r + 128 < BN) { CV_ST(sb_hi, st_r + 128, bh2); CV_ST(sb_lo, st_r + 128, bl2); } \
     }
 
-    f32x4_t acc[2][NF];
+    f32x4_t acc[MF][NFW];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MF; ++m)
 #pragma unroll
-        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NFW; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // fragment addressing: lane -> (row/col = lane & 15, k group = lane >> 4): 16 B at byte (lane>>4)*16
-    const int frow = lane & 15, fk = (lane >> 4) * 16;
-    const unsigned char* a_base_hi = a_hi + (wv * 32 + frow) * CV_LDS_ROW + fk;
-    const unsigned char* a_base_lo = a_lo + (wv * 32 + frow) * CV_LDS_ROW + fk;
-    const unsigned char* b_base_hi = b_hi + frow * CV_LDS_ROW + fk;
-    const unsigned char* b_base_lo = b_lo + frow * CV_LDS_ROW + fk;
+    // fragment addressing: lane -> (row/col = lane & 15, K slot = lane >> 4); every fragment's first row is a
+    // multiple of 16, so the swizzle term depends on the lane only
+    const int frow = lane & 15;
+    const int a_off = cv_swz(wm * (MF * 16) + frow, lane >> 4);       // + m*16*CV_ROW
+    const int b_off = cv_swz(wn * (NFW * 16) + frow, lane >> 4);      // + n*16*CV_ROW
 
     CV_ISSUE(0)
-    CV_COMMIT()
+    CV_COMMIT(0)
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         if (s + 1 < nsteps) CV_ISSUE(s + 1)                   // next step's global loads fly during the MFMAs
-        bf16x8_t ah[2], al[2];
+        const unsigned char* sa_hi = smem + (s & 1) * STAGE_BYTES;
+        const unsigned char* sa_lo = sa_hi + A_BYTES;
+        const unsigned char* sb_hi = sa_hi + 2 * A_BYTES;
+        const unsigned char* sb_lo = sb_hi + B_BYTES;
+        bf16x8_t ah[MF], al[MF];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            ah[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_base_hi + m * 16 * CV_LDS_ROW));
-            al[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_base_lo + m * 16 * CV_LDS_ROW));
+        for (int m = 0; m < MF; ++m) {
+            ah[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa_hi + a_off + m * 16 * CV_ROW));
+            al[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa_lo + a_off + m * 16 * CV_ROW));
         }
 #pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b_base_hi + n * 16 * CV_LDS_ROW));
-            const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b_base_lo + n * 16 * CV_LDS_ROW));
+        for (int n = 0; n < NFW; ++n) {
+            const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
+            const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_lo + b_off + n * 16 * CV_ROW));
+            // term-major order: consecutive MFMAs write DIFFERENT accumulators (a dependent MFMA on the same
+            // accumulator waits out the full pipeline latency); small terms first
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh, acc[m][n], 0, 0, 0);   // small terms first
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
-            }
+            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh, acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
         }
-        __syncthreads();                                      // everyone is done reading this step's tiles
-        if (s + 1 < nsteps) {
-            CV_COMMIT()
-            __syncthreads();
-        }
+        // the other buffer was last read in step s-1, and every wave has passed that step's barrier
+        if (s + 1 < nsteps) CV_COMMIT((s + 1) & 1)
+        __syncthreads();
     }
 
-    // ---- epilogue through LDS, one 16-row fragment per wave at a time: [16 rows][BN] fp32 per wave ----
-    float* stage = reinterpret_cast<float*>(smem) + wv * (16 * (BN + 4));   // +4 floats row pad
-    constexpr int SROW = BN + 4;
+    // ---- epilogue through LDS, one 16-row fragment per wave at a time: [16 rows][NFW*16] fp32 per wave ----
+    constexpr int WCOLS = NFW * 16, SROW = WCOLS + 4;          // +4 floats row pad
+    float* stage = reinterpret_cast<float*>(smem) + wv * (16 * SROW);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {                             // fully unrolled: acc indices stay static
+    for (int m = 0; m < MF; ++m) {                            // fully unrolled: acc indices stay static
         __syncthreads();
 #pragma unroll
-        for (int n = 0; n < NF; ++n)
+        for (int n = 0; n < NFW; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 stage[((lane >> 4) * 4 + r) * SROW + n * 16 + (lane & 15)] = acc[m][n][r];   // C: col = lane&15, row = (lane>>4)*4+r
         __syncthreads();
-        // 16 rows x BN channels, 8 channels (one 16-byte bf16 vector / two fp32 vectors) per work item
-        for (int it = lane; it < 16 * (BN / 8); it += 64) {
-            const int r = it / (BN / 8), c8 = (it % (BN / 8)) * 8;
-            const long long row = row0 + wv * 32 + m * 16 + r;
+        // 16 rows x WCOLS channels, 8 channels (one 16-byte bf16 vector / two fp32 vectors) per work item
+        for (int it = lane; it < 16 * (WCOLS / 8); it += 64) {
+            const int r = it / (WCOLS / 8), c8 = (it % (WCOLS / 8)) * 8;
+            const long long row = row0 + wm * (MF * 16) + m * 16 + r;
             if (row >= p.rows) continue;
+            const int ch = n0 + wn * WCOLS + c8;
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float x = stage[r * SROW + c8 + i] + p.bias[n0 + c8 + i];
+                float x = stage[r * SROW + c8 + i] + p.bias[ch + i];
                 v[i] = (p.relu && x < 0.f) ? 0.f : x;
             }
-            const size_t e = (size_t)row * p.cout_pad + n0 + c8;
+            const size_t e = (size_t)row * p.cout_pad + ch;
             if (p.out_mode == 0) {
                 uint32_t h[4], l[4];
 #pragma unroll
@@ -199,24 +226,180 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 }
 
-template <int NF>
+template <int NF, int WN, int BM>
 static size_t conv_lds_bytes() {
-    const size_t tiles = 2 * (size_t)CV_BM * CV_LDS_ROW + 2 * (size_t)(NF * 16) * CV_LDS_ROW;
-    const size_t stage = (size_t)4 * 16 * (NF * 16 + 4) * 4;
+    const size_t tiles = 2 * (2 * (size_t)BM * CV_ROW + 2 * (size_t)(NF * 16) * CV_ROW);
+    const size_t stage = (size_t)4 * 16 * ((NF / WN) * 16 + 4) * 4;
     return tiles > stage ? tiles : stage;
 }
 
-template <int NF>
+template <int NF, int WN, int BM>
 static hipError_t launch_conv_nf(const ConvParams& p, hipStream_t s) {
-    const dim3 grid((unsigned)((p.rows + CV_BM - 1) / CV_BM), (unsigned)(p.cout_pad / (NF * 16))), block(256);
-    hipLaunchKernelGGL((conv_mfma_kernel<NF>), grid, block, conv_lds_bytes<NF>(), s, p);
+    const dim3 grid((unsigned)((p.rows + BM - 1) / BM), (unsigned)(p.cout_pad / (NF * 16))), block(256);
+    const size_t lds = conv_lds_bytes<NF, WN, BM>();
+    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
-    if (p.cout_pad % 128 == 0) return launch_conv_nf<8>(p, s);
-    if (p.cout_pad == 144)     return launch_conv_nf<9>(p, s);
-    if (p.cout_pad == 16)      return launch_conv_nf<1>(p, s);
+    // 128 channels: 2x2 waves of 64x64 on a 128-row tile.  (A 256-row tile — one wave per SIMD, 96 MFMAs per K
+    // step and wave — measured SLOWER on MI355X: 3.45 vs 2.78 ms on the G-Net 3x3 layer; template kept for reference.)
+    if (p.cout_pad % 128 == 0) return launch_conv_nf<8, 2, 128>(p, s);
+    if (p.cout_pad == 144) return launch_conv_nf<9, 1, 128>(p, s);
+    if (p.cout_pad == 16)  return launch_conv_nf<1, 1, 128>(p, s);
+    return hipErrorInvalidValue;
+}
+
+// =====================================================================================================
+// Fused tail of a stack: Conv1x1(128->128)+ReLU, Conv1x1(128->128)+ReLU, Conv1x1(128->cout) in ONE kernel.
+// As separate launches these layers are HBM-bound (each reads and writes a (rows,128) split-bf16 tensor:
+// 1.3 GB per layer per 64-frame launch).  Here a workgroup keeps its 128-row activation tile in LDS across
+// the three layers; only the (rows,128) input is read and the (rows,cout) fp32 result written.
+//   * 4 waves, each owns 32 rows of the tile for all layers (rows are wave-private: no barrier is needed
+//     to hand a layer's output to the next layer, only for the shared weight tiles);
+//   * operands are swapped (weights as the MFMA A operand, activations as B), so the accumulator layout is
+//     C^T: a lane holds 4 CONSECUTIVE output channels of one row -> 8-byte bf16x4 LDS writes for hidden
+//     layers, 16-byte fp32 global stores for the last one;
+//   * activation tile rows are 256 B with slot ^= (row & 15) (conflict-free fragment reads); weight tiles are
+//     streamed per 32-wide K chunk through the same double-buffered swizzled image as conv_mfma_kernel.
+struct ChainParams {
+    const uint16_t* in_hi;  const uint16_t* in_lo;    // (rows, 128)
+    const uint16_t* w_hi;   const uint16_t* w_lo;     // [128][128], [128][128], [cout_pad][128] concatenated
+    const float*    bias;                             // 128 + 128 + cout_pad
+    float*          out;                              // (rows, cout_pad) fp32
+    long long rows;
+    int cout_pad;
+};
+
+__device__ __forceinline__ int act_swz(int row, int slot) { return row * 256 + ((slot ^ (row & 15)) << 4); }
+
+// one layer: acc[n][m] over K = 128 for this wave's 32 rows; NF = output fragments (channels / 16)
+template <int NF, bool LAST>
+__device__ __forceinline__ void chain_layer(const ChainParams& p, const uint16_t* __restrict__ w_hi,
+                                            const uint16_t* __restrict__ w_lo, const float* __restrict__ bias,
+                                            unsigned char* act_hi, unsigned char* act_lo, unsigned char* wst,
+                                            long long row0, int tid, int lane, int wv) {
+    constexpr int BN = NF * 16;
+    constexpr int B_BYTES = BN * CV_ROW, WSTAGE = 2 * B_BYTES;
+    constexpr int B_PT = (BN * 4 + 255) / 256;
+    static_assert(B_PT <= 3, "weight staging registers are spelled out for these sizes");
+    const int st_r = tid >> 2, st_q = tid & 3;
+    uint4 bh0, bh1, bh2, bl0, bl1, bl2;
+    bh1 = bh2 = bl1 = bl2 = make_uint4(0, 0, 0, 0);
+#define CH_ISSUE(KK)                                                                               \
+    {                                                                                              \
+        const size_t e0 = (size_t)(st_r < BN ? st_r : 0) * 128 + (KK) * 32 + st_q * 8;             \
+        bh0 = *reinterpret_cast<const uint4*>(w_hi + e0); bl0 = *reinterpret_cast<const uint4*>(w_lo + e0); \
+        if constexpr (B_PT >= 2) { const size_t e1 = (size_t)(st_r + 64 < BN ? st_r + 64 : 0) * 128 + (KK) * 32 + st_q * 8;  \
+            bh1 = *reinterpret_cast<const uint4*>(w_hi + e1); bl1 = *reinterpret_cast<const uint4*>(w_lo + e1); }            \
+        if constexpr (B_PT >= 3) { const size_t e2 = (size_t)(st_r + 128 < BN ? st_r + 128 : 0) * 128 + (KK) * 32 + st_q * 8; \
+            bh2 = *reinterpret_cast<const uint4*>(w_hi + e2); bl2 = *reinterpret_cast<const uint4*>(w_lo + e2); }            \
+    }
+#define CH_COMMIT(BUF)                                                                             \
+    {                                                                                              \
+        unsigned char* sb_hi = wst + (BUF) * WSTAGE; unsigned char* sb_lo = sb_hi + B_BYTES;       \
+        if (st_r < BN) { *reinterpret_cast<uint4*>(sb_hi + cv_swz(st_r, st_q)) = bh0;             \
+                         *reinterpret_cast<uint4*>(sb_lo + cv_swz(st_r, st_q)) = bl0; }            \
+        if constexpr (B_PT >= 2) if (st_r + 64 < BN) { *reinterpret_cast<uint4*>(sb_hi + cv_swz(st_r + 64, st_q)) = bh1;    \
+                                                       *reinterpret_cast<uint4*>(sb_lo + cv_swz(st_r + 64, st_q)) = bl1; }  \
+        if constexpr (B_PT >= 3) if (st_r + 128 < BN) { *reinterpret_cast<uint4*>(sb_hi + cv_swz(st_r + 128, st_q)) = bh2;  \
+                                                        *reinterpret_cast<uint4*>(sb_lo + cv_swz(st_r + 128, st_q)) = bl2; } \
+    }
+    f32x4_t acc[NF][2];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) { acc[n][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[n][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    const int frow = lane & 15, kslot = lane >> 4;
+    const int w_off = cv_swz(frow, kslot);                              // + n*16*CV_ROW
+    CH_ISSUE(0)
+    __syncthreads();                                                    // previous layer is done with the weight stage
+    CH_COMMIT(0)
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        if (kk + 1 < 4) CH_ISSUE(kk + 1)
+        const unsigned char* sb_hi = wst + (kk & 1) * WSTAGE;
+        const unsigned char* sb_lo = sb_hi + B_BYTES;
+        bf16x8_t xh[2], xl[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int row = wv * 32 + m * 16 + frow;
+            xh[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_hi + act_swz(row, kk * 4 + kslot)));
+            xl[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_lo + act_swz(row, kk * 4 + kslot)));
+        }
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const bf16x8_t wh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + w_off + n * 16 * CV_ROW));
+            const bf16x8_t wl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_lo + w_off + n * 16 * CV_ROW));
+            // swapped operands: D = W_frag (rows = channels) x act_frag (cols = tile rows)  ->  C^T
+            acc[n][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[0], acc[n][0], 0, 0, 0);
+            acc[n][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[1], acc[n][1], 0, 0, 0);
+            acc[n][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[0], acc[n][0], 0, 0, 0);
+            acc[n][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[1], acc[n][1], 0, 0, 0);
+            acc[n][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[0], acc[n][0], 0, 0, 0);
+            acc[n][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[1], acc[n][1], 0, 0, 0);
+        }
+        if (kk + 1 < 4) CH_COMMIT((kk + 1) & 1)
+        __syncthreads();
+    }
+    // epilogue: C^T layout — lane: channels n*16 + (lane>>4)*4 + r (r = 0..3), tile row m*16 + (lane & 15)
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int ch = n * 16 + (lane >> 4) * 4;
+            const int trow = wv * 32 + m * 16 + (lane & 15);
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + ch);
+            float v[4] = {acc[n][m][0] + b4.x, acc[n][m][1] + b4.y, acc[n][m][2] + b4.z, acc[n][m][3] + b4.w};
+            if constexpr (!LAST) {
+                uint16_t h[4], l[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = v[r] < 0.f ? 0.f : v[r]; split_bf16(v[r], h[r], l[r]); }
+                const int off = act_swz(trow, ch >> 3) + (ch & 7) * 2;          // 8 bytes: channels ch..ch+3
+                *reinterpret_cast<uint2*>(act_hi + off) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                *reinterpret_cast<uint2*>(act_lo + off) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+            } else {
+                const long long row = row0 + trow;
+                if (row < p.rows)
+                    *reinterpret_cast<float4*>(p.out + (size_t)row * p.cout_pad + ch) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+#undef CH_ISSUE
+#undef CH_COMMIT
+}
+
+template <int NFL>
+__global__ __launch_bounds__(256) void conv1x1_chain_kernel(const ChainParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* act_hi = smem;                      // [128 rows][256 B]
+    unsigned char* act_lo = smem + 128 * 256;
+    unsigned char* wst    = smem + 2 * 128 * 256;      // 2 stages x (hi, lo) x [max(128, NFL*16) rows][64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long row0 = (long long)blockIdx.x * 128;
+    // each wave loads its own 32 rows (x 16 slots x 2 planes)
+    for (int i = lane; i < 32 * 16; i += 64) {
+        const int r = wv * 32 + (i >> 4), slot = i & 15;
+        long long row = row0 + r; row = row < p.rows ? row : p.rows - 1;
+        const size_t e = (size_t)row * 128 + slot * 8;
+        *reinterpret_cast<uint4*>(act_hi + act_swz(r, slot)) = *reinterpret_cast<const uint4*>(p.in_hi + e);
+        *reinterpret_cast<uint4*>(act_lo + act_swz(r, slot)) = *reinterpret_cast<const uint4*>(p.in_lo + e);
+    }
+    chain_layer<8, false>(p, p.w_hi, p.w_lo, p.bias, act_hi, act_lo, wst, row0, tid, lane, wv);
+    chain_layer<8, false>(p, p.w_hi + 128 * 128, p.w_lo + 128 * 128, p.bias + 128, act_hi, act_lo, wst, row0, tid, lane, wv);
+    chain_layer<NFL, true>(p, p.w_hi + 2 * 128 * 128, p.w_lo + 2 * 128 * 128, p.bias + 256, act_hi, act_lo, wst, row0, tid, lane, wv);
+}
+
+template <int NFL>
+static hipError_t launch_chain_nf(const ChainParams& p, hipStream_t s) {
+    constexpr int BNMAX = (NFL * 16 > 128) ? NFL * 16 : 128;
+    const size_t lds = 2 * 128 * 256 + 2 * 2 * (size_t)BNMAX * CV_ROW;
+    hipLaunchKernelGGL((conv1x1_chain_kernel<NFL>), dim3((unsigned)((p.rows + 127) / 128)), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv1x1_chain(const ChainParams& p, hipStream_t s) {
+    if (p.cout_pad == 16)  return launch_chain_nf<1>(p, s);
+    if (p.cout_pad == 144) return launch_chain_nf<9>(p, s);
+    if (p.cout_pad == 128) return launch_chain_nf<8>(p, s);
     return hipErrorInvalidValue;
 }
 

@@ -333,3 +333,24 @@ def upsample_depth_cl(depth, mask_pad, ld, out=None):
         _check(lib.magnet_upsample_depth_cl(d.data_ptr(), _dev(mask_pad, "mask_pad", torch.float32).data_ptr(), int(ld),
                                             out.data_ptr(), B, h, w, _stream(d)), "magnet_upsample_depth_cl")
     return out
+
+
+API_SYMBOLS = API_SYMBOLS + ("magnet_conv1x1_chain",)
+
+
+def conv1x1_chain(in_hi, in_lo, w_hi, w_lo, bias, out, rows, cout_pad):
+    """relu(1x1 128->128), relu(1x1 128->128), 1x1 128->cout_pad in one launch (see include/magnet_hip.h)."""
+    lib = _conv_protos(load())
+    if not getattr(lib, "_chain_proto", False):
+        P = ctypes.c_void_p
+        lib.magnet_conv1x1_chain.restype = ctypes.c_int
+        lib.magnet_conv1x1_chain.argtypes = [P, P, P, P, P, P, ctypes.c_int64, ctypes.c_int32, P]
+        lib._chain_proto = True
+    for t, n in ((in_hi, "in_hi"), (in_lo, "in_lo"), (w_hi, "w_hi"), (w_lo, "w_lo")):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+            raise MagnetError(f"conv1x1_chain: {n} must be a contiguous bf16 GPU tensor")
+    with torch.cuda.device(in_hi.device):
+        _check(lib.magnet_conv1x1_chain(in_hi.data_ptr(), in_lo.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(),
+                                        _dev(bias, "bias", torch.float32).data_ptr(),
+                                        _dev(out, "out", torch.float32).data_ptr(), int(rows), int(cout_pad),
+                                        _stream(in_hi)), "magnet_conv1x1_chain")

@@ -16,12 +16,13 @@ def _stack(cin, cout_last, seed):
     return seq.eval()
 
 
-def _run_stack(seq, x, gpu, in_map=None):
+def _run_stack(seq, x, gpu, in_map=None, fuse_tail=True):
     """x: (B, C, h, w) fp32 CPU -> interior of the stack's fp32 output, (B, cout, h, w)."""
     from magnet_amd import lib
     from magnet_amd.convnet import ConvStackMFMA
     B, C, h, w = x.shape
     st = ConvStackMFMA(seq.to(gpu), in_map=in_map)
+    st.fuse_tail = fuse_tail
     ctot = st.cin_pad()
     rows = B * (h + 2) * (w + 2)
     hi = torch.zeros((rows, ctot), dtype=torch.bfloat16, device=gpu); lo = torch.zeros_like(hi)
@@ -37,15 +38,16 @@ def _run_stack(seq, x, gpu, in_map=None):
     return o
 
 
+@pytest.mark.parametrize("fuse_tail", [True, False])
 @pytest.mark.parametrize("cin,cout,h,w,B", [(320, 2, 12, 16, 2), (256, 144, 9, 21, 1), (64, 2, 30, 40, 3)])
-def test_conv_stack_matches_fp32(hip_lib, gpu, cin, cout, h, w, B):
+def test_conv_stack_matches_fp32(hip_lib, gpu, cin, cout, h, w, B, fuse_tail):
     seq = _stack(cin, cout, seed=cin + cout)
     x = torch.randn(B, cin, h, w, generator=torch.Generator().manual_seed(5))
     with torch.no_grad():
         ref = seq(x)
-    got = _run_stack(seq, x, gpu)
+    got = _run_stack(seq, x, gpu, fuse_tail=fuse_tail)
     err = (got - ref).abs().max().item(); scale = ref.abs().max().item()
-    print(f"[conv {cin}->{cout}] max|d|={err:.3e} max|ref|={scale:.3f} rel={err / scale:.2e}")
+    print(f"[conv {cin}->{cout} fused_tail={fuse_tail}] max|d|={err:.3e} max|ref|={scale:.3f} rel={err / scale:.2e}")
     assert torch.isfinite(got).all() and err <= 2e-5 * max(1.0, scale)
 
 
