@@ -105,6 +105,7 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
         return fail(MAGNET_E_DTYPE, "magnet_cost_volume_cw: unknown feat_dtype %d", a->feat_dtype);
     if (!aligned16(a->ref_feat_cl) || !aligned16(a->src_feat_pad))
         return fail(MAGNET_E_ALIGN, "magnet_cost_volume_cw: feature pointers must be 16-byte aligned");
+    if (a->V > 64) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: V=%d exceeds 64 source views", a->V);
     if ((size_t)a->h * a->w * (size_t)a->F * (size_t)a->V * (size_t)a->B >= ((size_t)1 << 40))
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: problem too large");
 

@@ -114,6 +114,12 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
     const unsigned char* __restrict__ ref_row = reinterpret_cast<const unsigned char*>(p.ref_feat) +
         ((size_t)b * hw + (size_t)yc * p.w) * texel_bytes;                        // reference features of this pixel row
     const float fV = (float)p.V;
+    // view validity (homography.py:97) as a bitmask read ONCE: a load inside the loop cannot be hoisted past the
+    // kernel's global stores and costs a full memory round trip per (pixel, view) iteration
+    unsigned long long vmask = 0ull;
+    for (int v = 0; v < p.V; ++v) vmask |= (unsigned long long)(p.is_valid[b * p.V + v] == 1) << v;
+    vmask = __builtin_amdgcn_readfirstlane((uint32_t)vmask) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(vmask >> 32)) << 32);
+    CGmmPair g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};              // tap registers (only leader lanes' values are ever read)
 
     for (int jb = 0; jb < JB; ++jb) {                                             // candidate block of DL candidates
         const int j = jb * DL + j0;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
             double acc = 0.0;
 
             for (int v = 0; v < p.V; ++v) {
-                if (p.is_valid[b * p.V + v] != 1) continue;                      // homography.py:97 (uniform)
+                if (!((vmask >> v) & 1ull)) continue;                            // homography.py:97 (wave-uniform)
                 const size_t sidx = (size_t)v * p.B + b;                         // view-major, homography.py:105
                 const unsigned char* __restrict__ src =
                     reinterpret_cast<const unsigned char*>(p.src_feat) + sidx * (size_t)Hp * Wp * texel_bytes;
@@ -176,7 +182,6 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)KEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);  // wave_shr:1
                 if (j0 == 0) tprev = KEY_CLOSED;                                  // first candidate of a pixel group
                 const bool lead = inwin && (tkey != tprev);
-                CGmmPair g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
                 if (lead && !(p.ablate & 2)) {
                     g0 = *reinterpret_cast<const CGmmPair*>(sgm + qi * 8u);
                     g1 = *reinterpret_cast<const CGmmPair*>(sgm + (qi + (uint32_t)Wp) * 8u);
