@@ -14,7 +14,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$out/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
-        if "conv_mfma_kernel<8>" not in k: continue
+        if "conv_mfma_kernel<8" not in k: continue
         # split 3x3 vs 1x1 by grid? use LDS/duration unknown -> bucket by counter magnitude later
         agg[r["Counter_Name"]][r["Dispatch_Id"]]=float(r["Counter_Value"])
 import statistics
