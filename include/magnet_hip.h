@@ -82,6 +82,11 @@ typedef struct MagnetCostVolumeArgs {
     int64_t        cost_batch_stride;      /* elements between consecutive frames of `cost`; 0 = D*h*w (dense).
                                               Lets the kernel write the first D channels of G-Net's
                                               (B, D+256, h, w) input directly (models/MAGNET.py:167). */
+    void          *cost_hi, *cost_lo;      /* optional second output form (candidate-lane kernel only): the cost volume as
+                                              split-bf16 planes (hi = bf16(c), lo = bf16(c - hi)) in the conv kernel's
+                                              zero-bordered channel-last layout, element [((b*(h+2)+y+1)*(w+2)+x+1)*cost_ld + j].
+                                              When set, `cost` may be NULL (nothing is written there). */
+    int64_t        cost_ld;                /* row pitch (elements) of cost_hi / cost_lo */
 } MagnetCostVolumeArgs;
 
 MAGNET_API int magnet_version(void);

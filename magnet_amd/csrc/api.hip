@@ -92,7 +92,7 @@ MAGNET_API int magnet_pack_gmm(const float* gmm_nchw, float* out_pad, int32_t N,
 MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream) {
     if (!a) return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: args is NULL");
     if (!a->ref_feat_cl || !a->src_feat_pad || !a->src_gmm_pad || !a->poses || !a->is_valid || !a->intM ||
-        !a->rays || !a->cost)
+        !a->rays || (!a->cost && !a->cost_hi))
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: a required pointer is NULL");
     if (!a->d_volume && (!a->ref_gmm || !a->k_list))
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: d_volume is NULL, so ref_gmm and k_list are required");
@@ -122,6 +122,11 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
     p.ref_feat = a->ref_feat_cl; p.src_feat = a->src_feat_pad; p.src_gmm = a->src_gmm_pad;
     p.ref_gmm = a->ref_gmm; p.d_volume = a->d_volume; p.poses = a->poses; p.is_valid = a->is_valid;
     p.intM = a->intM; p.rays = a->rays; p.cost = a->cost; p.stats = a->stats;
+    p.cost_hi = (uint16_t*)a->cost_hi; p.cost_lo = (uint16_t*)a->cost_lo; p.cost_ld = a->cost_ld;
+    if (a->cost_hi && (!a->cost_lo || a->cost_ld < a->D))
+        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: cost_hi needs cost_lo and cost_ld >= D");
+    if (a->cost_hi && (a->path & 0xff) != 0 && (a->path & 0xff) != 2)
+        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the split channel-last output exists only in the candidate-lane kernel (path 0/2)");
     p.cost_bstride = a->cost_batch_stride ? a->cost_batch_stride : (long long)a->D * a->h * a->w;
     if (p.cost_bstride < (long long)a->D * a->h * a->w)
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: cost_batch_stride smaller than D*h*w");
@@ -145,6 +150,7 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: unknown path %d", path);
     }
     if (!handled) {
+        if (a->cost_hi) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: this shape falls back to the generic kernel, which has no split output");
         e = magnet::launch_cv_generic(p, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw generic launch");
     }

@@ -261,7 +261,18 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 }
                 wave_lds_fence();                                                 // ctab/items are rewritten by the next view
             }
-            outb[(q & (OUT_PX - 1)) * DL + j0] = (float)acc / fV;                 // homography.py:118,120
+            const float cval = (float)acc / fV;                                   // homography.py:118,120
+            if (p.cost_hi) {
+                // split-bf16 channel-last output for the conv kernel: lanes = consecutive channels of one row
+                if (live) {
+                    const uint16_t hi = f32_to_bf16_rne(cval);
+                    const uint16_t lo = f32_to_bf16_rne(cval - bf16_to_f32(hi));
+                    const size_t e = (((size_t)b * Hp + (y + 1)) * Wp + (x + 1)) * (size_t)p.cost_ld + j;
+                    p.cost_hi[e] = hi; p.cost_lo[e] = lo;
+                }
+                continue;
+            }
+            outb[(q & (OUT_PX - 1)) * DL + j0] = cval;
             if ((((qb + 1) * PPW) & (OUT_PX - 1)) == 0) {
                 // ---- OUT_PX px x DL results: LDS -> coalesced row segments of cost[b, j, y, :] ----
                 const int q_base = (qb + 1) * PPW - OUT_PX;

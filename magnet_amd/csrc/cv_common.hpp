@@ -29,6 +29,9 @@ struct CvParams {
     float*         cost;
     uint32_t*      stats;
     long long      cost_bstride;      // elements between frames of `cost`
+    uint16_t*      cost_hi;           // optional split-bf16 channel-last output (see include/magnet_hip.h)
+    uint16_t*      cost_lo;
+    long long      cost_ld;
     float k[MAGNET_MAX_CANDIDATES];   // (float)k_j, read with wave-uniform indices (scalar loads)
 };
 

@@ -41,6 +41,7 @@ class MagnetCostVolumeArgs(ctypes.Structure):
         ("cost", ctypes.c_void_p),
         ("path", ctypes.c_int32), ("stats", ctypes.c_void_p),
         ("cost_batch_stride", ctypes.c_int64),
+        ("cost_hi", ctypes.c_void_p), ("cost_lo", ctypes.c_void_p), ("cost_ld", ctypes.c_int64),
     ]
 
 
@@ -142,7 +143,7 @@ def pack_gmm(gmm_nchw: torch.Tensor, out: torch.Tensor | None = None):
 
 
 def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM, rays, kappa,
-                   ref_gmm=None, k_list=None, d_volume=None, out=None, path: int = 0, stats=None):
+                   ref_gmm=None, k_list=None, d_volume=None, out=None, path: int = 0, stats=None, out_split=None):
     """Launch the fused matching kernel.  All tensors on one GPU; see MagnetCostVolumeArgs.
 
     ref_feat_cl (B,h,w,F) from pack_features(pad=0); src_feat_pad (V*B,h+2,w+2,F) from
@@ -191,7 +192,14 @@ def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM
         raise MagnetError("poses/is_valid/intM/rays shape mismatch: "
                           f"{tuple(po.shape)} {tuple(iv.shape)} {tuple(K.shape)} {tuple(ry.shape)}")
     a.poses, a.is_valid, a.intM, a.rays = po.data_ptr(), iv.data_ptr(), K.data_ptr(), ry.data_ptr()
-    if out is None:
+    if out_split is not None:
+        # (hi, lo, ld): split-bf16 planes of the conv kernel's zero-bordered channel-last buffer, written in place
+        oh, ol, ld = out_split
+        for t in (oh, ol):
+            if not t.is_cuda or t.dtype != torch.bfloat16:
+                raise MagnetError("out_split planes must be bf16 GPU tensors")
+        a.cost_hi, a.cost_lo, a.cost_ld = oh.data_ptr(), ol.data_ptr(), int(ld)
+    elif out is None:
         out = torch.empty((B, D, h, w), dtype=torch.float32, device=r.device)
     else:
         # `out` may be the leading-D-channel slice of a larger (B, D+C, h, w) buffer (G-Net's input)
@@ -200,7 +208,8 @@ def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM
         if out.stride()[1:] != (h * w, w, 1) or (B > 1 and out.stride(0) < D * h * w):
             raise MagnetError(f"out strides {out.stride()} unsupported (need dense (D,h,w) frames)")
         a.cost_batch_stride = out.stride(0) if B > 1 else 0
-    a.cost = out.data_ptr()
+    if out_split is None:
+        a.cost = out.data_ptr()
     a.path = int(path)
     if stats is not None:
         a.stats = _dev(stats, "stats").data_ptr()

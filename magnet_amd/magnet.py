@@ -200,8 +200,12 @@ class MAGNET(nn.Module):
         mask_pad, mask_ld = m_stack.run(gin_hi[:, Dp:], gin_lo[:, Dp:], ctot, rows, wp, work)       # MAGNET.py:172
         pred_list = [ref_gmms.detach().float().contiguous()]
         for _ in range(n_iter):
-            matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out=work["cost"])                    # MAGNET.py:153-164
-            lib.pack_split(work["cost"], gin_hi, gin_lo, ctot, 0)
+            if self.matcher_path in (0, 2):
+                # the candidate-lane kernel writes the D cost channels of the G-Net input buffer directly
+                matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out_split=(gin_hi, gin_lo, ctot))  # MAGNET.py:153-164
+            else:
+                matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out=work["cost"])
+                lib.pack_split(work["cost"], gin_hi, gin_lo, ctot, 0)
             g_out, g_ld = g_stack.run(gin_hi, gin_lo, ctot, rows, wp, work)                          # MAGNET.py:62
             pred_list.append(lib.gaussian_update_cl(g_out, g_ld, pred_list[-1], h, w))               # MAGNET.py:60-69
         return [lib.upsample_depth_cl(pred, mask_pad, mask_ld) for pred in pred_list[1:]]            # MAGNET.py:173

@@ -181,6 +181,30 @@ def test_cost_volume_strided_output_into_gnet_buffer(hip_lib, gpu):
         assert torch.equal(buf[:, :5], dense) and torch.all(buf[:, 5:] == 7.0)
 
 
+def test_cost_volume_split_channel_last_output(hip_lib, gpu):
+    """cost_hi/cost_lo: the matcher writes split-bf16 planes of the conv kernel's zero-bordered channel-last buffer.
+    Must equal splitting the fp32 cost volume, touch only the D cost channels of interior rows, for D = 64 and D = 5."""
+    from magnet_amd.convnet import split_bf16
+    from magnet_amd.homography import CostVolumeCW
+    for D, F in ((64, 16), (5, 8)):
+        wl = synth.Workload("sp", "scannet", 13, 19, V=2, D=D, F=F)
+        inp = synth.make_inputs(wl, B=2, seed=11)
+        d = to_dev(inp, gpu)
+        k = oracle.depth_sampling(3, D)
+        cv = CostVolumeCW(d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"], d["cam_intrins"], 5)
+        dense = cv(ref_gmm=d["ref_gmms"], k_list=k)                                    # (B,D,h,w) fp32
+        ld = 96
+        rows = 2 * 15 * 21
+        hi = torch.full((rows, ld), 7.0, dtype=torch.bfloat16, device=gpu); lo = torch.full_like(hi, 7.0)
+        cv(ref_gmm=d["ref_gmms"], k_list=k, out_split=(hi, lo, ld))
+        eh, el = split_bf16(dense.permute(0, 2, 3, 1).contiguous())                    # (B,h,w,D)
+        hi4 = hi.view(2, 15, 21, ld); lo4 = lo.view(2, 15, 21, ld)
+        assert torch.equal(hi4[:, 1:-1, 1:-1, :D], eh) and torch.equal(lo4[:, 1:-1, 1:-1, :D], el)
+        poison = torch.full((1,), 7.0, dtype=torch.bfloat16, device=gpu)
+        assert torch.all(hi4[:, 1:-1, 1:-1, D:] == poison) and torch.all(hi4[:, 0] == poison) and torch.all(hi4[:, :, 0] == poison)
+        assert torch.all(lo4[:, -1] == poison) and torch.all(lo4[:, :, -1] == poison)
+
+
 def test_linearity_in_reference_features(hip_lib, gpu):
     """Size-independent property at the full C2 shape: the score is linear in the reference
     features for fixed gates (scaling ref features by 2 scales the cost volume by exactly 2)."""
