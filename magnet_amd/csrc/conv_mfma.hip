@@ -77,7 +77,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
-    const long long row0 = (long long)blockIdx.x * CV_BM;
+    // XCD-aware tile order: hardware deals consecutive block ids round-robin to the 8 XCDs; remap so each XCD (one
+    // private L2) owns a contiguous run of row tiles — vertically adjacent tiles share their halo rows (bijective).
+    long long tile_id;
+    {
+        const unsigned n = gridDim.x, bid = blockIdx.x, q = n / 8, r = n % 8, xcd = bid % 8, idx = bid / 8;
+        tile_id = (long long)((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long row0 = tile_id * CV_BM;
     const int n0 = blockIdx.y * BN;
 
     // staging: a 64-byte K-slice of one row = 4 x 16 B; thread -> (row, quarter), +64 / +128 rows for more
@@ -91,15 +98,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const int nsteps = p.taps * ksteps_per_tap;
     const int st_r = tid >> 2, st_q = tid & 3;
 
+    // step order: K-chunk outer, tap inner — the 9 taps of one 32-channel chunk re-read (shifted) the same 64-byte
+    // row slices back to back, a working set of ~50 KB per workgroup that stays in the XCD's L2; tap-major order
+    // swept 164 KB per workgroup between re-reads (x64 resident workgroups >> 4 MiB L2).
     auto a_elem = [&](int s, int i) -> size_t {
-        const int tap = s / ksteps_per_tap, k0 = (s % ksteps_per_tap) * CV_BK;
+        const int tap = s % p.taps, k0 = (s / p.taps) * CV_BK;
         const int off = (p.taps == 9) ? ((tap / 3 - 1) * p.wp + (tap % 3 - 1)) : 0;
         long long row = row0 + st_r + i * 64 + off;
         row = row < 0 ? 0 : (row >= p.rows ? p.rows - 1 : row);        // guard rows only feed border outputs
         return (size_t)row * p.in_ld + k0 + st_q * 8;
     };
     auto b_elem = [&](int s, int i) -> size_t {
-        const int tap = s / ksteps_per_tap, k0 = (s % ksteps_per_tap) * CV_BK;
+        const int tap = s % p.taps, k0 = (s / p.taps) * CV_BK;
         const int r = st_r + i * 64;
         return ((size_t)tap * p.cout_pad + n0 + (r < BN ? r : 0)) * p.cin + k0 + st_q * 8;
     };
