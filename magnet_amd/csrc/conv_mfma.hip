@@ -87,16 +87,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const long long row0 = tile_id * CV_BM;
     const int n0 = blockIdx.y * BN;
 
-    // staging: a 64-byte K-slice of one row = 4 x 16 B; thread -> (row, quarter), +64 / +128 rows for more
+    // staging by LDS-DMA (global_load_lds_dwordx4: global -> LDS without a VGPR round trip or ds_write): a
+    // 64-byte K-slice of one row = 4 x 16 B; thread -> (row = tid>>2 (+64, +128 ...), physical slot = tid&3).  The DMA
+    // writes lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the SOURCE: the lane
+    // that fills physical slot ps of row r fetches logical K slot ps ^ ((r>>1)&3)  (cdna_hip_programming.md rule 21).
     constexpr int B_PT = (BN * 4 + 255) / 256;                 // 16-byte vectors per thread per B plane
-    static_assert(B_PT <= 3, "staging registers below are spelled out for these sizes");
-    // explicit scalars: arrays here end up in scratch memory (the compiler does not promote them)
-    uint4 ah0, ah1, ah2, ah3, al0, al1, al2, al3, bh0, bh1, bh2, bl0, bl1, bl2;
-    bh1 = bh2 = bl1 = bl2 = ah2 = ah3 = al2 = al3 = make_uint4(0, 0, 0, 0);
-
     const int ksteps_per_tap = p.cin / CV_BK;
     const int nsteps = p.taps * ksteps_per_tap;
     const int st_r = tid >> 2, st_q = tid & 3;
+    const int st_k = (st_q ^ ((st_r >> 1) & 3)) * 8;           // logical K offset (elements) this lane fetches
+    const int wave_row = __builtin_amdgcn_readfirstlane(wv * 16);   // first tile row this wave's DMA instruction fills
 
     // step order: K-chunk outer, tap inner — the 9 taps of one 32-channel chunk re-read (shifted) the same 64-byte
     // row slices back to back, a working set of ~50 KB per workgroup that stays in the XCD's L2; tap-major order
@@ -106,45 +106,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         const int off = (p.taps == 9) ? ((tap / 3 - 1) * p.wp + (tap % 3 - 1)) : 0;
         long long row = row0 + st_r + i * 64 + off;
         row = row < 0 ? 0 : (row >= p.rows ? p.rows - 1 : row);        // guard rows only feed border outputs
-        return (size_t)row * p.in_ld + k0 + st_q * 8;
+        return (size_t)row * p.in_ld + k0 + st_k;
     };
     auto b_elem = [&](int s, int i) -> size_t {
         const int tap = s % p.taps, k0 = (s / p.taps) * CV_BK;
-        const int r = st_r + i * 64;
-        return ((size_t)tap * p.cout_pad + n0 + (r < BN ? r : 0)) * p.cin + k0 + st_q * 8;
+        return ((size_t)tap * p.cout_pad + n0 + st_r + i * 64) * p.cin + k0 + st_k;
     };
-#define CV_LD(ptr, e) (*reinterpret_cast<const uint4*>((ptr) + (e)))
-#define CV_ISSUE(S)                                                                       \
-    {                                                                                     \
-        const size_t ea0 = a_elem((S), 0), ea1 = a_elem((S), 1);                          \
-        ah0 = CV_LD(p.in_hi, ea0); al0 = CV_LD(p.in_lo, ea0);                             \
-        ah1 = CV_LD(p.in_hi, ea1); al1 = CV_LD(p.in_lo, ea1);                             \
-        if constexpr (A_PT == 4) {                                                        \
-            const size_t ea2 = a_elem((S), 2), ea3 = a_elem((S), 3);                      \
-            ah2 = CV_LD(p.in_hi, ea2); al2 = CV_LD(p.in_lo, ea2);                         \
-            ah3 = CV_LD(p.in_hi, ea3); al3 = CV_LD(p.in_lo, ea3);                         \
-        }                                                                                 \
-        const size_t eb0 = b_elem((S), 0);                                                \
-        bh0 = CV_LD(p.w_hi, eb0); bl0 = CV_LD(p.w_lo, eb0);                               \
-        if constexpr (B_PT >= 2) { const size_t eb1 = b_elem((S), 1); bh1 = CV_LD(p.w_hi, eb1); bl1 = CV_LD(p.w_lo, eb1); } \
-        if constexpr (B_PT >= 3) { const size_t eb2 = b_elem((S), 2); bh2 = CV_LD(p.w_hi, eb2); bl2 = CV_LD(p.w_lo, eb2); } \
-    }
-#define CV_ST(base, r, v) (*reinterpret_cast<uint4*>((base) + cv_swz((r), st_q)) = (v))
-#define CV_COMMIT(BUF)                                                                    \
-    {                                                                                     \
-        unsigned char* sa_hi = smem + (BUF) * STAGE_BYTES;                                \
-        unsigned char* sa_lo = sa_hi + A_BYTES;                                           \
-        unsigned char* sb_hi = sa_hi + 2 * A_BYTES;                                       \
-        unsigned char* sb_lo = sb_hi + B_BYTES;                                           \
-        CV_ST(sa_hi, st_r, ah0); CV_ST(sa_lo, st_r, al0);                                 \
-        CV_ST(sa_hi, st_r + 64, ah1); CV_ST(sa_lo, st_r + 64, al1);                       \
-        if constexpr (A_PT == 4) {                                                        \
-            CV_ST(sa_hi, st_r + 128, ah2); CV_ST(sa_lo, st_r + 128, al2);                 \
-            CV_ST(sa_hi, st_r + 192, ah3); CV_ST(sa_lo, st_r + 192, al3);                 \
-        }                                                                                 \
-        if (st_r < BN) { CV_ST(sb_hi, st_r, bh0); CV_ST(sb_lo, st_r, bl0); }              \
-        if constexpr (B_PT >= 2) if (st_r + 64 < BN) { CV_ST(sb_hi, st_r + 64, bh1); CV_ST(sb_lo, st_r + 64, bl1); }   \
-        if constexpr (B_PT >= 3) if (st_r + 128 < BN) { CV_ST(sb_hi, st_r + 128, bh2); CV_ST(sb_lo, st_r + 128, bl2); } \
+    typedef const void __attribute__((address_space(1)))* gptr_t;
+    typedef void __attribute__((address_space(3)))* lptr_t;
+#define CV_GLDS(gp, lp) __builtin_amdgcn_global_load_lds((gptr_t)(gp), (lptr_t)(lp), 16, 0, 0)
+#define CV_DMA(S, BUF)                                                                                 \
+    {                                                                                                  \
+        unsigned char* sa_hi = smem + (BUF) * STAGE_BYTES;                                             \
+        unsigned char* sa_lo = sa_hi + A_BYTES;                                                        \
+        unsigned char* sb_hi = sa_hi + 2 * A_BYTES;                                                    \
+        unsigned char* sb_lo = sb_hi + B_BYTES;                                                        \
+        _Pragma("unroll") for (int i = 0; i < A_PT; ++i) {                                             \
+            const size_t e = a_elem((S), i);                                                           \
+            CV_GLDS(p.in_hi + e, sa_hi + (wave_row + i * 64) * CV_ROW);                                \
+            CV_GLDS(p.in_lo + e, sa_lo + (wave_row + i * 64) * CV_ROW);                                \
+        }                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < B_PT; ++i) {                                             \
+            if (st_r + i * 64 < BN) {                                                                  \
+                const size_t e = b_elem((S), i);                                                       \
+                CV_GLDS(p.w_hi + e, sb_hi + (wave_row + i * 64) * CV_ROW);                             \
+                CV_GLDS(p.w_lo + e, sb_lo + (wave_row + i * 64) * CV_ROW);                             \
+            }                                                                                          \
+        }                                                                                              \
     }
 
     f32x4_t acc[MF][NFW];
@@ -159,11 +147,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const int a_off = cv_swz(wm * (MF * 16) + frow, lane >> 4);       // + m*16*CV_ROW
     const int b_off = cv_swz(wn * (NFW * 16) + frow, lane >> 4);      // + n*16*CV_ROW
 
-    CV_ISSUE(0)
-    CV_COMMIT(0)
-    __syncthreads();
+    CV_DMA(0, 0)
+    __syncthreads();                                          // drains the DMA (vmcnt) and publishes stage 0
     for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) CV_ISSUE(s + 1)                   // next step's global loads fly during the MFMAs
+        // the other LDS stage was last read in step s-1 and every wave has passed that step's barrier: refill it
+        // now, the DMA flies during this step's MFMAs
+        if (s + 1 < nsteps) CV_DMA(s + 1, (s + 1) & 1)
         const unsigned char* sa_hi = smem + (s & 1) * STAGE_BYTES;
         const unsigned char* sa_lo = sa_hi + A_BYTES;
         const unsigned char* sb_hi = sa_hi + 2 * A_BYTES;
@@ -187,9 +176,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
         }
-        // the other buffer was last read in step s-1, and every wave has passed that step's barrier
-        if (s + 1 < nsteps) CV_COMMIT((s + 1) & 1)
-        __syncthreads();
+        __syncthreads();                                      // DMA of step s+1 landed; everyone done with stage s&1
     }
 
     // ---- epilogue through LDS, one 16-row fragment per wave at a time: [16 rows][NFW*16] fp32 per wave ----
@@ -456,9 +443,7 @@ hipError_t launch_pack_split(const float* in, uint16_t* out_hi, uint16_t* out_lo
     return hipGetLastError();
 }
 
-#undef CV_ISSUE
-#undef CV_COMMIT
-#undef CV_LD
-#undef CV_ST
+#undef CV_DMA
+#undef CV_GLDS
 
 }  // namespace magnet
