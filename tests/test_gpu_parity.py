@@ -136,6 +136,37 @@ def test_cost_volume_ragged_grid_and_odd_D(hip_lib, gpu):
         assert_cost_parity(got, orc, path=path, label="ragged")
 
 
+@pytest.mark.parametrize("V,D,F,fdt", [(6, 24, 32, "bf16"), (1, 256, 8, "fp32"), (3, 40, 128, "fp32"), (2, 9, 128, "bf16"),
+                                        (8, 16, 72, "fp32")])
+def test_cost_volume_shape_sweep(hip_lib, gpu, V, D, F, fdt):
+    """Channel counts off the F = 64 fast path (partial / multi-chunk lanes), D up to the ABI limit, many views."""
+    wl = synth.Workload("sweep", "7scenes", 10, 23, V=V, D=D, F=F)
+    inp = synth.make_inputs(wl, B=2, seed=V * 100 + D, round_bf16=(fdt == "bf16"), invalid=[(1, 0)])
+    k = oracle.depth_sampling(3, D)
+    orc = oracle_cost(inp, k)
+    for path in (0, 1) + ((3,) if D <= 128 else ()):
+        got = _hip_cost(inp, k, gpu, feat_dtype=fdt, path=path)
+        assert_cost_parity(got, orc, path=path, label=f"sweep V={V} D={D} F={F} {fdt}")
+
+
+def test_cost_volume_nan_and_degenerate_inputs(hip_lib, gpu):
+    """NaN / zero sigma / zero depth in the reference gmm and a singular pose: the reference's arithmetic yields 0
+    for those samples (closed gate, out-of-range sample); every kernel must agree with the oracle and stay finite."""
+    wl = synth.Workload("nan", "scannet", 12, 16, V=2, D=8, F=8)
+    inp = synth.make_inputs(wl, B=2, seed=21)
+    inp["ref_gmms"][0, 0, 3, 4] = float("nan")          # mu NaN
+    inp["ref_gmms"][0, 1, 5, 6] = float("nan")          # sigma NaN
+    inp["ref_gmms"][1, 1, 2, :] = 0.0                   # sigma 0: all candidates identical
+    inp["ref_gmms"][1, 0, 7, :] = 0.0                   # depth 0
+    inp["nghbr_poses"][1, 1, :3, :3] = 0.0              # singular rotation
+    k = oracle.depth_sampling(3, 8)
+    orc = oracle_cost(inp, k)
+    assert np.isfinite(orc).all()
+    for path in (0, 1, 3):
+        got = _hip_cost(inp, k, gpu, path=path)
+        assert_cost_parity(got, orc, path=path, label="nan/degenerate")
+
+
 def test_cost_volume_all_views_invalid_is_zero(hip_lib, gpu):
     wl = synth.Workload("inv", "scannet", 12, 16, V=2, D=5, F=8)
     inp = synth.make_inputs(wl, B=1, seed=5, invalid=[(0, 0), (0, 1)])
