@@ -11,6 +11,8 @@
  *                               + the candidate sampling in front of it (models/MAGNET.py:153-156)
  *   magnet_gaussian_update   -> the element-wise tail of GNET.forward (models/MAGNET.py:60-69)
  *   magnet_upsample_depth    -> upsample_depth_via_mask       (models/MAGNET.py:15-27)
+ *   magnet_depth_metrics     -> utils.compute_depth_errors + validate()'s masking (utils/utils.py:106-144,
+ *                               test_MaGNet.py:43,58-79), so full depth maps never leave the device
  *   magnet_conv_mfma (+ magnet_pack_split, magnet_gaussian_update_cl, magnet_upsample_depth_cl)
  *                            -> the g_net / mask_head nn.Conv2d stacks (models/MAGNET.py:51-56,111-116)
  *
@@ -161,6 +163,14 @@ MAGNET_API int magnet_gaussian_update_cl(const float *gnet_out_pad, int32_t ld, 
  * (B, h+2, w+2, ld), channel n*k*k + i*k + j as in models/MAGNET.py:19; depth (B,2,h,w) -> out (B,2,4h,4w); k = 4. */
 MAGNET_API int magnet_upsample_depth_cl(const float *depth, const float *mask_pad, int32_t ld, float *out,
                                         int32_t B, int32_t h, int32_t w, void *stream);
+
+/* Depth-error reductions on the device (utils.compute_depth_errors, utils/utils.py:106-144, with the masking /
+ * clamping of test_MaGNet.py:43,58-79): pred (B,2,H*W) [mu, sigma], gt (B,H*W).  sums: OUT double (B,16), zeroed by
+ * the call: n, sum|d|, sum|d|/gt, sum d^2/gt, sum d^2, sum(ln gt-ln p)^2, sum(ln p-ln gt), sum|log10 gt-log10 p|,
+ * sum(1/gt-1/p)^2, #(t<1.25), #(t<1.25^2), #(t<1.25^3), sum nll, 0,0,0.  The 12 metrics are ratios of these
+ * (magnet_amd/metrics.py). */
+MAGNET_API int magnet_depth_metrics(const float *pred, const float *gt, double *sums, int32_t B, int32_t HW,
+                                    float min_depth, float max_depth, void *stream);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,7 @@ hipError_t launch_conv1x1_chain(const ChainParams&, hipStream_t);
 hipError_t launch_pack_split(const float*, uint16_t*, uint16_t*, int, int, int, int, int, int, long long, hipStream_t);
 hipError_t launch_gaussian_update_cl(const float*, int, const float*, float*, int, int, int, hipStream_t);
 hipError_t launch_upsample_cl(const float*, const float*, int, float*, int, int, int, hipStream_t);
+hipError_t launch_depth_metrics(const float*, const float*, double*, int, int, float, float, hipStream_t);
 }
 
 static thread_local char g_err[512] = "";
@@ -240,6 +241,14 @@ MAGNET_API int magnet_upsample_depth_cl(const float* depth, const float* mask_pa
     if (!aligned16(out) || !aligned16(mask_pad)) return fail(MAGNET_E_ALIGN, "magnet_upsample_depth_cl: pointers not 16-byte aligned");
     hipError_t e = magnet::launch_upsample_cl(depth, mask_pad, ld, out, B, h, w, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_upsample_depth_cl launch");
+}
+
+MAGNET_API int magnet_depth_metrics(const float* pred, const float* gt, double* sums, int32_t B, int32_t HW, float min_depth,
+                                    float max_depth, void* stream) {
+    if (!pred || !gt || !sums) return fail(MAGNET_E_NULL, "magnet_depth_metrics: NULL pointer");
+    if (B <= 0 || HW <= 0 || !(max_depth > min_depth)) return fail(MAGNET_E_DIM, "magnet_depth_metrics: bad arguments");
+    hipError_t e = magnet::launch_depth_metrics(pred, gt, sums, B, HW, min_depth, max_depth, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_depth_metrics launch");
 }
 
 }  // extern "C"

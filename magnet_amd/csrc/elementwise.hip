@@ -197,6 +197,61 @@ hipError_t launch_upsample_cl(const float* d, const float* m, int ld, float* o, 
     return hipGetLastError();
 }
 
+// ---- depth metrics (utils.compute_depth_errors, utils/utils.py:106-144 + the masking of test_MaGNet.py:43,58-79) ----
+// Per frame: sums over valid pixels (min < gt < max) of the terms each metric averages; fp64 accumulation
+// (thread -> wave DPP-free shuffle -> block LDS -> one atomicAdd per block and term).
+// sums[b][0..15] = n, |d|, |d|/gt, d^2/gt, d^2, (ln gt - ln p)^2, (ln p - ln gt), |log10 gt - log10 p|,
+//                  (1/gt - 1/p)^2, [t<1.25], [t<1.25^2], [t<1.25^3], nll term, 0, 0, 0      with d = gt - p, t = max(gt/p, p/gt)
+constexpr int MET_N = 16;
+__global__ __launch_bounds__(256) void depth_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                             double* __restrict__ sums, int HW, float dmin, float dmax) {
+    const int b = blockIdx.y;
+    double acc[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) acc[i] = 0.0;
+    const float* mu = pred + (size_t)b * 2 * HW;
+    const float* sg = mu + HW;
+    const float* g = gt + (size_t)b * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        float gv = g[i];
+        if (gv > dmax) gv = 0.f;                                       // test_MaGNet.py:43
+        if (!(gv > dmin && gv < dmax)) continue;                       // test_MaGNet.py:58
+        float pv = mu[i];
+        pv = pv < dmin ? dmin : pv; pv = pv > dmax ? dmax : pv;        // test_MaGNet.py:72-75 (inf -> max, nan -> min)
+        if (isinf(pv)) pv = dmax;
+        if (isnan(pv)) pv = dmin;
+        const double G = gv, P = pv, d = G - P;
+        const double lg = log(G), lp = log(P);
+        const double t = fmax(G / P, P / G);
+        double var = (double)sg[i] * (double)sg[i];
+        var = var < 1e-6 ? 1e-6 : var;                                 // utils.py:134
+        acc[0] += 1.0; acc[1] += fabs(d); acc[2] += fabs(d) / G; acc[3] += d * d / G; acc[4] += d * d;
+        acc[5] += (lg - lp) * (lg - lp); acc[6] += (lp - lg); acc[7] += fabs(log10(G) - log10(P));
+        acc[8] += (1.0 / G - 1.0 / P) * (1.0 / G - 1.0 / P);
+        acc[9] += (t < 1.25) ? 1.0 : 0.0; acc[10] += (t < 1.25 * 1.25) ? 1.0 : 0.0; acc[11] += (t < 1.25 * 1.25 * 1.25) ? 1.0 : 0.0;
+        acc[12] += 0.5 * (log(var) + 1.8378770664093453 + d * d / var);    // ln(2 pi)
+    }
+    __shared__ double red[4][13];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 13) atomicAdd(sums + (size_t)b * MET_N + threadIdx.x,
+                                    red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+hipError_t launch_depth_metrics(const float* pred, const float* gt, double* sums, int B, int HW, float dmin, float dmax, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)B * MET_N * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    const int nb = (HW + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(depth_metrics_kernel, dim3((unsigned)(nb < 1 ? 1 : nb), (unsigned)B), dim3(256), 0, s, pred, gt, sums, HW, dmin, dmax);
+    return hipGetLastError();
+}
+
 // ---- learned convex upsampling -------------------------------------------------------------------
 // One thread per coarse pixel; lanes run along x so every mask-plane read is coalesced; the k
 // sub-pixels of one output row are stored as one contiguous run per lane (16 B for k = 4).

@@ -363,3 +363,6 @@ def conv1x1_chain(in_hi, in_lo, w_hi, w_lo, bias, out, rows, cout_pad):
                                         _dev(bias, "bias", torch.float32).data_ptr(),
                                         _dev(out, "out", torch.float32).data_ptr(), int(rows), int(cout_pad),
                                         _stream(in_hi)), "magnet_conv1x1_chain")
+
+
+API_SYMBOLS = API_SYMBOLS + ("magnet_depth_metrics",)

@@ -95,3 +95,47 @@ def test_gaussian_update_and_upsample_cl(hip_lib, gpu):
     mp[:, 1:-1, 1:-1] = m.permute(0, 2, 3, 1)
     got = lib.upsample_depth_cl(d.to(gpu), mp.to(gpu).view(-1, 144), 144).cpu().numpy()
     np.testing.assert_allclose(got, oracle.upsample_depth_via_mask(d.numpy(), m.numpy(), 4), rtol=0, atol=5e-6)
+
+
+def test_depth_metrics_match_reference(hip_lib, gpu, golden):
+    """Device reductions vs utils.compute_depth_errors (G7 golden values) incl. validate()'s clamping/masking."""
+    from magnet_amd import metrics as M
+    from oracle import oracle
+    gt = torch.from_numpy(golden["G7_gt"]); pr = torch.from_numpy(golden["G7_pred"]); var = torch.from_numpy(golden["G7_var"])
+    n = gt.numel()
+    pred = torch.stack([pr, var.sqrt()], 0).view(1, 2, 1, n)
+    m = M.compute_depth_errors(pred.to(gpu), gt.view(1, 1, 1, n).to(gpu), 1e-3, 10.0)[0]
+    for k, v in zip(golden["G7_keys"], golden["G7_vals"]):
+        assert abs(m[str(k)] - v) <= 2e-5 * max(1.0, abs(v)), (k, m[str(k)], v)
+    # masking + clamping as in test_MaGNet.py:43,58-79
+    g = torch.Generator().manual_seed(4)
+    gt2 = torch.rand(2, 1, 24, 32, generator=g) * 12                       # some > max_depth -> invalid
+    gt2[0, 0, :3] = 0.0
+    pr2 = torch.rand(2, 2, 24, 32, generator=g) * 11 + 0.01
+    pr2[0, 0, 5, 5] = float("inf"); pr2[1, 0, 6, 6] = float("nan"); pr2[1, 0, 7, 7] = -1.0
+    got = M.compute_depth_errors(pr2.to(gpu), gt2.to(gpu), 1e-3, 10.0)
+    for b in range(2):
+        gtn = gt2[b, 0].numpy().copy(); gtn[gtn > 10.0] = 0.0
+        mask = np.logical_and(gtn > 1e-3, gtn < 10.0)
+        pn = pr2[b, 0].numpy().copy()
+        pn[pn < 1e-3] = 1e-3; pn[pn > 10.0] = 10.0; pn[np.isinf(pn)] = 10.0; pn[np.isnan(pn)] = 1e-3
+        ref = oracle.compute_depth_errors(gtn[mask], pn[mask], np.square(pr2[b, 1].numpy())[mask])
+        for k in M.METRIC_ORDER:
+            assert abs(got[b][k] - float(ref[k])) <= 2e-5 * max(1.0, abs(float(ref[k]))), (b, k, got[b][k], ref[k])
+
+
+def test_eval_driver_runs(hip_lib, gpu, tmp_path):
+    """The test_MaGNet.py-shaped loop end to end on tiny synthetic windows (one NaN pose -> a dropped view)."""
+    import eval_synthetic as E
+    from magnet_amd.magnet import MAGNET
+    from tests.stubs import StubDNet, StubFNet, make_args, seeded_magnet_weights
+    args = make_args(D=5, iters=2, dpv_h=12, dpv_w=16, V=2)
+    args.min_depth, args.max_depth = 1e-3, 10.0
+    model = MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2, fdim=8))
+    seeded_magnet_weights(model, 3)
+    model = model.to(gpu).eval()
+    loader = E.SyntheticWindows(2, 2, 2, 48, 64, nan_every=1)
+    m = E.validate(model, args, loader, gpu)
+    assert set(m.keys()) == set(E.M.METRIC_ORDER) and all(np.isfinite(v) for v in m.values())
+    E.M.log_metrics(str(tmp_path / "test_acc.txt"), m, "synthetic")
+    assert (tmp_path / "test_acc.txt").read_text().count("\n") == 4

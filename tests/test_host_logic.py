@@ -62,3 +62,29 @@ def test_magnet_forward_refuses_cpu():
     with pytest.raises(lib.MagnetError):
         m(img, torch.rand(2, 3, 48, 64), synth.make_poses("scannet", 1, 2, torch.Generator().manual_seed(0)),
           torch.ones(1, 2, dtype=torch.int32), synth.make_intrinsics("scannet", 12, 16, 1), mode="test")
+
+
+def test_data_preprocess_matches_reference(golden):
+    """G8: relative poses / validity of utils.data_preprocess incl. a NaN reference and a NaN neighbour."""
+    from magnet_amd.preprocess import data_preprocess, split_data_array
+    exts = golden["G8_exts"]
+    data_array = [{"extM": torch.from_numpy(e), "tag": i} for i, e in enumerate(exts)]
+    ref, nghbrs, poses, valid = data_preprocess(data_array, 3)
+    assert ref["tag"] == 2 and [d["tag"] for d in nghbrs] == [0, 1, 3, 4]          # middle frame is the reference
+    assert poses.dtype == torch.float32 and valid.dtype == torch.int32 and not poses.is_cuda
+    np.testing.assert_allclose(poses.numpy(), golden["G8_poses"], rtol=0, atol=1e-6)
+    assert np.array_equal(valid.numpy(), golden["G8_valid"])
+    assert split_data_array(data_array)[0]["tag"] == 2
+
+
+def test_metrics_from_sums_and_log_format(tmp_path):
+    from magnet_amd import metrics as M
+    m = M.metrics_from_sums([4, 2.0, 1.0, 0.5, 1.0, 0.04, 0.2, 0.3, 0.16, 3, 4, 4, 2.0, 0, 0, 0])
+    assert m["abs_diff"] == 0.5 and m["abs_rel"] == 0.25 and m["rmse"] == 0.5 and m["a1"] == 0.75 and m["nll"] == 0.5
+    path = tmp_path / "log.txt"
+    M.log_metrics(str(path), m, "first line")
+    lines = path.read_text().splitlines()
+    assert lines[0] == "first line" and lines[1] == "abs_rel abs_diff sq_rel rmse rmse_log irmse log_10 silog a1 a2 a3 NLL"
+    assert len(lines[2].split()) == 12 and lines[2].split()[0] == "0.2500"
+    r = M.RunningAverageDict(); r.update({"a": 1.0}); r.update({"a": 3.0})
+    assert r.get_value()["a"] == 2.0
