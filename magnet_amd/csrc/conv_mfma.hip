@@ -63,7 +63,8 @@ __device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) 
 
 // NF = 16-column fragments of the workgroup tile (BN = NF*16: 128, 144 or 16 channels);
 // WN = waves along N (2: 2x2 waves; 1: 4x1 waves); CV_BM = rows of the workgroup tile (128 or 256)
-template <int NF, int WN, int CV_BM>
+// SPB = K stages per barrier interval (the LDS ring holds 2*SPB stages)
+template <int NF, int WN, int CV_BM, int SPB>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int BN = NF * 16;
     constexpr int A_PT = CV_BM / 64;                           // 16-byte vectors per thread per A plane (2 or 4)
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     static_assert(NF % WN == 0, "N fragments must split evenly over the waves");
     constexpr int A_BYTES = CV_BM * CV_ROW, B_BYTES = BN * CV_ROW;
     constexpr int STAGE_BYTES = 2 * A_BYTES + 2 * B_BYTES;    // hi + lo planes of A and B
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two stages (double buffer)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // ring of 2*SPB stages
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
@@ -147,13 +148,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const int a_off = cv_swz(wm * (MF * 16) + frow, lane >> 4);       // + m*16*CV_ROW
     const int b_off = cv_swz(wn * (NFW * 16) + frow, lane >> 4);      // + n*16*CV_ROW
 
-    CV_DMA(0, 0)
-    __syncthreads();                                          // drains the DMA (vmcnt) and publishes stage 0
-    for (int s = 0; s < nsteps; ++s) {
-        // the other LDS stage was last read in step s-1 and every wave has passed that step's barrier: refill it
-        // now, the DMA flies during this step's MFMAs
-        if (s + 1 < nsteps) CV_DMA(s + 1, (s + 1) & 1)
-        const unsigned char* sa_hi = smem + (s & 1) * STAGE_BYTES;
+    // one K stage of MFMAs from ring slot BUF
+    auto compute = [&](int buf) {
+        const unsigned char* sa_hi = smem + buf * STAGE_BYTES;
         const unsigned char* sa_lo = sa_hi + A_BYTES;
         const unsigned char* sb_hi = sa_hi + 2 * A_BYTES;
         const unsigned char* sb_lo = sb_hi + B_BYTES;
@@ -176,7 +173,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
         }
-        __syncthreads();                                      // DMA of step s+1 landed; everyone done with stage s&1
+    };
+
+#pragma unroll
+    for (int q = 0; q < SPB; ++q)
+        if (q < nsteps) CV_DMA(q, q)
+    __syncthreads();                                          // drains the DMA (vmcnt) and publishes the first half
+    for (int s = 0, half = 0; s < nsteps; s += SPB, half ^= 1) {
+        // the other half of the ring was last read one interval ago and every wave has passed that barrier:
+        // refill it now, the DMA flies during this interval's MFMAs
+#pragma unroll
+        for (int q = 0; q < SPB; ++q)
+            if (s + SPB + q < nsteps) CV_DMA(s + SPB + q, (half ^ 1) * SPB + q)
+#pragma unroll
+        for (int q = 0; q < SPB; ++q)
+            if (s + q < nsteps) compute(half * SPB + q);
+        __syncthreads();                                      // next half landed; everyone done with this half
     }
 
     // ---- epilogue through LDS, one 16-row fragment per wave at a time: [16 rows][NFW*16] fp32 per wave ----
@@ -223,27 +235,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 }
 
-template <int NF, int WN, int BM>
+template <int NF, int WN, int BM, int SPB>
 static size_t conv_lds_bytes() {
-    const size_t tiles = 2 * (2 * (size_t)BM * CV_ROW + 2 * (size_t)(NF * 16) * CV_ROW);
+    const size_t tiles = 2 * SPB * (2 * (size_t)BM * CV_ROW + 2 * (size_t)(NF * 16) * CV_ROW);
     const size_t stage = (size_t)4 * 16 * ((NF / WN) * 16 + 4) * 4;
     return tiles > stage ? tiles : stage;
 }
 
-template <int NF, int WN, int BM>
+template <int NF, int WN, int BM, int SPB>
 static hipError_t launch_conv_nf(const ConvParams& p, hipStream_t s) {
     const dim3 grid((unsigned)((p.rows + BM - 1) / BM), (unsigned)(p.cout_pad / (NF * 16))), block(256);
-    const size_t lds = conv_lds_bytes<NF, WN, BM>();
-    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM>), grid, block, lds, s, p);
+    const size_t lds = conv_lds_bytes<NF, WN, BM, SPB>();
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {          // > 64 KiB of dynamic LDS needs the opt-in attribute
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM, SPB>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
-    // 128 channels: 2x2 waves of 64x64 on a 128-row tile.  (A 256-row tile — one wave per SIMD, 96 MFMAs per K
-    // step and wave — measured SLOWER on MI355X: 3.45 vs 2.78 ms on the G-Net 3x3 layer; template kept for reference.)
-    if (p.cout_pad % 128 == 0) return launch_conv_nf<8, 2, 128>(p, s);
-    if (p.cout_pad == 144) return launch_conv_nf<9, 1, 128>(p, s);
-    if (p.cout_pad == 16)  return launch_conv_nf<1, 1, 128>(p, s);
+    // 128 channels: 2x2 waves of 64x64 on a 128-row tile.
+    // Measured alternatives on the G-Net 3x3 layer (64 frames; this configuration: 2.31 ms): 64-row tile / 3 workgroups
+    // per CU 2.80 ms; two K stages per barrier (4-stage ring, 128 KB LDS, 1 workgroup per CU) 3.51 ms; 256-row tile
+    // (1 workgroup per CU) 3.45 ms.  The kernel lives on inter-workgroup overlap: keep 2 workgroups per CU.
+    if (p.cout_pad % 128 == 0) return launch_conv_nf<8, 2, 128, 1>(p, s);
+    if (p.cout_pad == 144) return launch_conv_nf<9, 1, 128, 1>(p, s);
+    if (p.cout_pad == 16)  return launch_conv_nf<1, 1, 128, 1>(p, s);
     return hipErrorInvalidValue;
 }
 
