@@ -137,6 +137,10 @@ typedef struct MagnetConvArgs {
     int32_t      relu, out_mode;
     int32_t      in_ld;                    /* elements between input rows (0 = cin): lets a layer read a channel slice
                                               of a wider buffer in place (pointer offset + in_ld) */
+    const float *addend;                   /* optional fp32 (rows, addend_ld): added to the accumulator before bias / ReLU.
+                                              Used to hoist the loop-invariant x_d3 part of G-Net's first layer out of
+                                              the refinement loop (models/MAGNET.py:151-168): W*[cost|x_d3] = Wc*cost + Wx*x_d3 */
+    int32_t      addend_ld;                /* row pitch of addend (0 = cout_pad) */
 } MagnetConvArgs;
 
 MAGNET_API int magnet_conv_mfma(const MagnetConvArgs *args, void *stream);

@@ -111,12 +111,48 @@ class ConvStackMFMA:
         self._packed, self._key = out, key
         return out
 
-    def run(self, in_hi, in_lo, in_ld, rows, wp, work):
+    @torch.no_grad()
+    def packed_first_split(self, device, n_var):
+        """First layer split by input channels of the (padded) input buffer: channels [0, n_var) vary per refinement
+        iteration (the cost volume), the rest is loop-invariant (x_d3).  Returns (variable part, invariant part):
+        variable = weights over buffer channels [0, round_up(n_var,32)) with the invariant positions zeroed (+ bias, ReLU);
+        invariant = weights over ALL buffer channels with the variable positions zeroed (no bias, no ReLU)."""
+        pk = self.packed(device)[0]
+        key = ("split", n_var, self._key)
+        if getattr(self, "_split_key", None) == key:
+            return self._split
+        w = (pk["w_hi"].float() + pk["w_lo"].float())                       # exact: hi + lo is how the kernel sees them
+        cv = _round_up(n_var, 32)
+        wv = w[:, :, :cv].clone(); wv[:, :, n_var:] = 0
+        wi = w.clone(); wi[:, :, :n_var] = 0
+        # split each part again from the ORIGINAL fp32 weights would be more accurate than re-splitting hi+lo, but
+        # hi+lo already carries 16 mantissa bits and re-splitting it is exact (hi, lo are recovered bit for bit)
+        vh, vl = split_bf16(wv.contiguous()); ih, il = split_bf16(wi.contiguous())
+        var = dict(w_hi=vh, w_lo=vl, bias=pk["bias"], taps=pk["taps"], cin=cv, cout_pad=pk["cout_pad"], relu=pk["relu"])
+        inv = dict(w_hi=ih, w_lo=il, bias=torch.zeros_like(pk["bias"]), taps=pk["taps"], cin=pk["cin"],
+                   cout_pad=pk["cout_pad"], relu=False)
+        self._split_key, self._split = key, (var, inv)
+        return self._split
+
+    def run_invariant(self, in_hi, in_lo, in_ld, rows, wp, work, n_var):
+        """Loop-invariant partial sums of the first layer: fp32 (rows, cout_pad), computed once per forward."""
+        _, inv = self.packed_first_split(in_hi.device, n_var)
+        key = ("partial", rows, inv["cout_pad"])
+        if key not in work:
+            work[key] = torch.empty((rows, inv["cout_pad"]), dtype=torch.float32, device=in_hi.device)
+        lib.conv_mfma(in_hi, in_lo, in_ld, inv["cin"], inv["w_hi"], inv["w_lo"], inv["bias"], inv["taps"], wp, False, rows,
+                      out_f32=work[key])
+        return work[key]
+
+    def run(self, in_hi, in_lo, in_ld, rows, wp, work, first_addend=None, n_var=None):
         """in_hi/in_lo: bf16 views whose data_ptr is row 0, channel 0 of this stack's input; `work`: dict for cached
         hidden buffers.  Returns (fp32 tensor (rows, cout_pad_last), cout_pad_last)."""
         packs = self.packed(in_hi.device)
+        if first_addend is not None:
+            # first layer over the per-iteration channels only; the invariant part arrives as `first_addend`
+            packs = [self.packed_first_split(in_hi.device, n_var)[0]] + list(packs[1:])
         cur_hi, cur_lo, cur_ld = in_hi, in_lo, in_ld
-        if self._chain is not None and self.fuse_tail:
+        if self._chain is not None and self.fuse_tail and first_addend is None:
             pk = packs[0]
             key = ("hid", 0, rows, 128)
             if key not in work:
@@ -166,7 +202,7 @@ class ConvStackMFMA:
                              torch.empty((rows, pk["cout_pad"]), dtype=torch.bfloat16, device=in_hi.device))
             oh, ol = work[key]
             lib.conv_mfma(cur_hi, cur_lo, cur_ld, pk["cin"], pk["w_hi"], pk["w_lo"], pk["bias"], pk["taps"], wp,
-                          pk["relu"], rows, out_hi=oh, out_lo=ol)
+                          pk["relu"], rows, out_hi=oh, out_lo=ol, addend=first_addend if li == 0 else None)
             if sink is not None:
                 e1.record()
             cur_hi, cur_lo, cur_ld = oh, ol, pk["cout_pad"]

@@ -20,6 +20,8 @@ struct ConvParams {
     long long rows;
     int cin, cout_pad, taps, wp, relu, out_mode;
     int in_ld;
+    const float* addend;
+    int addend_ld;
 };
 hipError_t launch_conv_mfma(const ConvParams&, hipStream_t);
 struct ChainParams {
@@ -196,6 +198,9 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     p.rows = a->rows; p.cin = a->cin; p.cout_pad = a->cout_pad; p.taps = a->taps; p.wp = a->wp;
     p.relu = a->relu; p.out_mode = a->out_mode;
     p.in_ld = a->in_ld ? a->in_ld : a->cin;
+    p.addend = a->addend; p.addend_ld = a->addend_ld ? a->addend_ld : a->cout_pad;
+    if (a->addend && (!aligned16(a->addend) || (p.addend_ld % 4) != 0 || p.addend_ld < a->cout_pad))
+        return fail(MAGNET_E_ALIGN, "magnet_conv_mfma: addend must be 16-byte aligned with addend_ld >= cout_pad, a multiple of 4");
     if (p.in_ld < a->cin || (p.in_ld % 8) != 0) return fail(MAGNET_E_DIM, "magnet_conv_mfma: in_ld=%d must be >= cin and a multiple of 8", p.in_ld);
     hipError_t e = magnet::launch_conv_mfma(p, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_conv_mfma launch");

@@ -38,6 +38,8 @@ struct ConvParams {
     long long rows;                                   // B*(h+2)*(w+2)
     int cin, cout_pad, taps, wp, relu, out_mode;
     int in_ld;                                        // elements between consecutive input rows (>= cin)
+    const float* addend;                              // optional fp32 (rows, addend_ld) added before bias/ReLU
+    int addend_ld;
 };
 
 constexpr int CV_BK = 32;
@@ -210,9 +212,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             if (row >= p.rows) continue;
             const int ch = n0 + wn * WCOLS + c8;
             float v[8];
+            float ad[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.addend) {                                   // loop-invariant partial sums computed once per forward
+                const float4 a0 = *reinterpret_cast<const float4*>(p.addend + (size_t)row * p.addend_ld + ch);
+                const float4 a1 = *reinterpret_cast<const float4*>(p.addend + (size_t)row * p.addend_ld + ch + 4);
+                ad[0] = a0.x; ad[1] = a0.y; ad[2] = a0.z; ad[3] = a0.w; ad[4] = a1.x; ad[5] = a1.y; ad[6] = a1.z; ad[7] = a1.w;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float x = stage[r * SROW + c8 + i] + p.bias[ch + i];
+                float x = (stage[r * SROW + c8 + i] + ad[i]) + p.bias[ch + i];
                 v[i] = (p.relu && x < 0.f) ? 0.f : x;
             }
             const size_t e = (size_t)row * p.cout_pad + ch;

@@ -260,6 +260,7 @@ class MagnetConvArgs(ctypes.Structure):
         ("rows", ctypes.c_int64),
         ("cin", ctypes.c_int32), ("cout_pad", ctypes.c_int32), ("taps", ctypes.c_int32), ("wp", ctypes.c_int32),
         ("relu", ctypes.c_int32), ("out_mode", ctypes.c_int32), ("in_ld", ctypes.c_int32),
+        ("addend", ctypes.c_void_p), ("addend_ld", ctypes.c_int32),
     ]
 
 
@@ -283,7 +284,8 @@ def _conv_protos(lib):
     return lib
 
 
-def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, out_hi=None, out_lo=None, out_f32=None):
+def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, out_hi=None, out_lo=None, out_f32=None,
+              addend=None):
     """One convolution layer on the matrix cores.  in_hi/in_lo: bf16 tensors whose data_ptr is row 0 (possibly a
     channel-offset view of a wider buffer, `in_ld` = its row pitch in elements); weights (taps, cout_pad, cin) bf16."""
     lib = _conv_protos(load())
@@ -295,6 +297,8 @@ def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, 
     a.bias = _dev(bias, "bias", torch.float32).data_ptr()
     a.rows, a.cin, a.cout_pad, a.taps, a.wp = int(rows), int(cin), int(w_hi.shape[1]), int(taps), int(wp)
     a.relu, a.in_ld = int(bool(relu)), int(in_ld)
+    if addend is not None:
+        a.addend, a.addend_ld = _dev(addend, "addend", torch.float32).data_ptr(), int(addend.shape[1])
     if out_f32 is not None:
         a.out_mode, a.out_f32 = 1, _dev(out_f32, "out_f32", torch.float32).data_ptr()
     else:

@@ -127,6 +127,7 @@ class MAGNET(nn.Module):
             raise lib.MagnetError(f"conv_backend must be 'mfma' or 'torch', got {conv_backend!r}")
         self.conv_backend = conv_backend
         self._work = {}                # cached device workspaces of the MFMA conv path, keyed by shape
+        self.hoist_invariant = True    # I >= 2: compute the x_d3 part of G-Net's first layer once per forward
         self._stacks = None
 
         dnet_fdim = 256
@@ -199,6 +200,10 @@ class MAGNET(nn.Module):
         lib.pack_split(x_d3.detach().float().contiguous(), gin_hi, gin_lo, ctot, Dp)
         mask_pad, mask_ld = m_stack.run(gin_hi[:, Dp:], gin_lo[:, Dp:], ctot, rows, wp, work)       # MAGNET.py:172
         pred_list = [ref_gmms.detach().float().contiguous()]
+        # With more than one refinement iteration the x_d3 part of G-Net's first layer (256 of the 256+D input
+        # channels) is loop-invariant: compute W_x * x_d3 once, add it in the epilogue of the per-iteration
+        # convolution over the D cost channels only (K = 9*(256+D) -> 9*round_up(D,32) per iteration).
+        partial = g_stack.run_invariant(gin_hi, gin_lo, ctot, rows, wp, work, Dp) if (n_iter >= 2 and self.hoist_invariant) else None
         for _ in range(n_iter):
             if self.matcher_path in (0, 2):
                 # the candidate-lane kernel writes the D cost channels of the G-Net input buffer directly
@@ -206,7 +211,7 @@ class MAGNET(nn.Module):
             else:
                 matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out=work["cost"])
                 lib.pack_split(work["cost"], gin_hi, gin_lo, ctot, 0)
-            g_out, g_ld = g_stack.run(gin_hi, gin_lo, ctot, rows, wp, work)                          # MAGNET.py:62
+            g_out, g_ld = g_stack.run(gin_hi, gin_lo, ctot, rows, wp, work, first_addend=partial, n_var=Dp)  # MAGNET.py:62
             pred_list.append(lib.gaussian_update_cl(g_out, g_ld, pred_list[-1], h, w))               # MAGNET.py:60-69
         return [lib.upsample_depth_cl(pred, mask_pad, mask_ld) for pred in pred_list[1:]]            # MAGNET.py:173
 

@@ -341,3 +341,28 @@ def test_full_loop_abs_rel_C3_shape(hip_lib, gpu, backend):
         ar = oracle.abs_rel(np.abs(c[:, 0]) + 1e-3, np.abs(got[:, 0]) + 1e-3)
         print(f"[C3 loop iter {i}] abs_rel delta = {ar:.3e}")
         assert np.isfinite(got).all() and ar < 1e-4
+
+
+def test_hoisted_invariant_conv_matches_unhoisted(hip_lib, gpu):
+    """I = 3: computing the x_d3 part of G-Net's first layer once per forward (hoist_invariant) must agree with
+    recomputing the full first layer every iteration, for D = 64 and the shipped D = 5."""
+    from magnet_amd.magnet import MAGNET
+    for D, fd in ((64, 16), (5, 8)):
+        wl = synth.Workload("h", "scannet", 12, 16, V=2, D=D, F=fd)
+        inp = synth.make_inputs(wl, B=2, seed=13)
+        d = to_dev(inp, gpu)
+        x_d3 = (torch.randn(2, 256, 12, 16, generator=torch.Generator().manual_seed(3)) * 0.5).to(gpu)
+        args = make_args(D=D, iters=3, dpv_h=12, dpv_w=16)
+        m = MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2, fdim=fd))
+        seeded_magnet_weights(m, seed=9)
+        m = m.to(gpu).eval()
+        outs = []
+        for hoist in (True, False):
+            m.hoist_invariant = hoist
+            with torch.no_grad():
+                outs.append([p.clone() for p in m.match_and_refine(d["ref_gmms"], x_d3, d["ref_feat"], d["nghbr_feat"],
+                                                                   d["nghbr_gmms"], d["nghbr_poses"], inp["is_valid"],
+                                                                   inp["cam_intrins"], mode="test")])
+        for a, b in zip(*outs):
+            assert torch.isfinite(a).all()
+            assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), (D, (a - b).abs().max().item())
