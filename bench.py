@@ -217,9 +217,11 @@ def main():
             "value": frames / elapsed, "unit": "ref-frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if fdt == "fp32" else "f32 (bf16-stored features)",
+            "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload_desc,
+                       "feature_storage": fdt, "arithmetic": "fp32 (fp64 view accumulation; convolutions bf16x3-split "
+                                                             "on the matrix cores with fp32 accumulation)",
                        "frames_per_gpu_per_step": B, "step": "kernel-only" if a.kernel_only else
                        ("pack + I x (fused cost volume + G-Net + Gaussian update) + mask head + convex upsample; convs on "
                         + ("the bf16x3 MFMA kernel" if a.conv_backend == "mfma" else "MIOpen fp32")),
@@ -246,7 +248,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(wl, model_cpu, iters)
         print(json.dumps(res))
     mdist.barrier()
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -21,9 +21,11 @@ def env_world():
 
 
 def init_from_env(backend: str | None = None):
-    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    """Initialise torch.distributed from the torchrun environment.  A plain `python bench.py` (no RANK in the
+    environment) stays single-process; under torchrun the group is created even for one rank, so the N = 1 launch
+    exercises the same rendezvous / RCCL path as N = 8."""
     rank, world, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
@@ -81,5 +83,5 @@ def sum_over_ranks(value: float, device=None) -> float:
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
