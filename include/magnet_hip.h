@@ -89,6 +89,12 @@ typedef struct MagnetCostVolumeArgs {
                                               zero-bordered channel-last layout, element [((b*(h+2)+y+1)*(w+2)+x+1)*cost_ld + j].
                                               When set, `cost` may be NULL (nothing is written there). */
     int64_t        cost_ld;                /* row pitch (elements) of cost_hi / cost_lo */
+    int32_t        mode;                   /* 0 = consistency-weighted matcher (est_costvolume_CW);
+                                              1 = plain feature-matching volume of est_costvolume_F / _compute_cost_F
+                                                  (homography.py:10-75) BEFORE its softmax: k_list holds the D fixed depth
+                                                  bins d_center (same for all pixels), there is no gate (src_gmm_pad,
+                                                  ref_gmm unused, may be NULL) and views are summed in fp32 (:42).
+                                                  Candidate-lane and generic kernels only. */
 } MagnetCostVolumeArgs;
 
 MAGNET_API int magnet_version(void);
@@ -107,6 +113,17 @@ MAGNET_API int magnet_pack_gmm(const float *gmm_nchw, float *out_pad, int32_t N,
 
 /* Consistency-weighted multi-view matching score, all (b, pixel, candidate) in one launch. */
 MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs *args, void *stream);
+
+/* Backward of mode 1 (what autograd derives for est_costvolume_F up to its softmax, homography.py:10-75,
+ * used by train_scripts/train_FNET/train.py): given grad_cost (B,D,h,w) = dL/d(cost before softmax) and
+ * the SAME args as the forward call (fp32 features, mode = 1; `cost` is ignored),
+ *   grad_ref_cl  (B,h,w,F)         fp32 channel-last, fully written;
+ *   grad_src_pad (V*B,h+2,w+2,F)   fp32 padded channel-last, ACCUMULATED into with atomics — zero it first;
+ *                                  what lands in the one-texel border is the (discarded) gradient of the
+ *                                  zero padding.
+ * Depth bins, poses and intrinsics receive no gradient (they are data in the reference's training loop). */
+MAGNET_API int magnet_cost_volume_f_backward(const MagnetCostVolumeArgs *args, const float *grad_cost, float *grad_ref_cl,
+                                  float *grad_src_pad, void *stream);
 
 /* gmm_out[:,0] = mu + o0*sigma ; gmm_out[:,1] = (elu(o1) + 1 + 1e-10)*sigma.   All (B,2,h*w) fp32.
  * gmm_out may alias gmm_in. */

@@ -92,12 +92,18 @@ MAGNET_API int magnet_pack_gmm(const float* gmm_nchw, float* out_pad, int32_t N,
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_pack_gmm launch");
 }
 
-MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream) {
+// argument checks + launch parameters shared by the matcher and the backward of its mode 1
+static int cv_prepare(const MagnetCostVolumeArgs* a, magnet::CvParams& p, bool backward) {
     if (!a) return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: args is NULL");
-    if (!a->ref_feat_cl || !a->src_feat_pad || !a->src_gmm_pad || !a->poses || !a->is_valid || !a->intM ||
-        !a->rays || (!a->cost && !a->cost_hi))
+    if (!a->ref_feat_cl || !a->src_feat_pad || (!a->src_gmm_pad && a->mode != 1) || !a->poses || !a->is_valid || !a->intM ||
+        !a->rays || (!backward && !a->cost && !a->cost_hi))
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: a required pointer is NULL");
-    if (!a->d_volume && (!a->ref_gmm || !a->k_list))
+    if (a->mode != 0 && a->mode != 1) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: unknown mode %d", a->mode);
+    if (a->mode == 1 && (!a->k_list || a->d_volume))
+        return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: mode 1 takes its depth bins from k_list (d_volume must be NULL)");
+    if (a->mode == 1 && (a->path & 0xff) == 3)
+        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: mode 1 is not implemented in the worklist kernel");
+    if (a->mode == 0 && !a->d_volume && (!a->ref_gmm || !a->k_list))
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: d_volume is NULL, so ref_gmm and k_list are required");
     if (a->B <= 0 || a->V <= 0 || a->F <= 0 || a->D <= 0 || a->h <= 0 || a->w <= 0)
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: non-positive dimension");
@@ -112,7 +118,6 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
     if ((size_t)a->h * a->w * (size_t)a->F * (size_t)a->V * (size_t)a->B >= ((size_t)1 << 40))
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: problem too large");
 
-    magnet::CvParams p;
     memset(&p, 0, sizeof(p));
     p.B = a->B; p.V = a->V; p.F = a->F; p.D = a->D; p.h = a->h; p.w = a->w;
     p.tiles_x = (a->w + magnet::TILE_W - 1) / magnet::TILE_W;
@@ -122,6 +127,7 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
     p.feat_bf16 = (a->feat_dtype == MAGNET_FEAT_BF16);
     p.kappa = a->kappa;
     p.ablate = (a->path >> 8) & 0xff;
+    p.mode_f = a->mode;
     p.ref_feat = a->ref_feat_cl; p.src_feat = a->src_feat_pad; p.src_gmm = a->src_gmm_pad;
     p.ref_gmm = a->ref_gmm; p.d_volume = a->d_volume; p.poses = a->poses; p.is_valid = a->is_valid;
     p.intM = a->intM; p.rays = a->rays; p.cost = a->cost; p.stats = a->stats;
@@ -135,7 +141,12 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: cost_batch_stride smaller than D*h*w");
     if (!a->d_volume)
         for (int j = 0; j < a->D; ++j) p.k[j] = (float)a->k_list[j];     // MAGNET.py:155: fp32 scalar multiply
+    return 0;
+}
 
+MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream) {
+    magnet::CvParams p;
+    if (const int rc = cv_prepare(a, p, false)) return rc;
     hipError_t e = hipSuccess;
     bool handled = false;
     const int path = a->path & 0xff;
@@ -157,6 +168,22 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
         e = magnet::launch_cv_generic(p, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw generic launch");
     }
+    return 0;
+}
+
+MAGNET_API int magnet_cost_volume_f_backward(const MagnetCostVolumeArgs* a, const float* grad_cost, float* grad_ref_cl,
+                                             float* grad_src_pad, void* stream) {
+    magnet::CvParams p;
+    if (const int rc = cv_prepare(a, p, true)) return rc;
+    if (a->mode != 1) return fail(MAGNET_E_DIM, "magnet_cost_volume_f_backward: only mode 1 (est_costvolume_F) is differentiable");
+    if (a->feat_dtype != MAGNET_FEAT_F32) return fail(MAGNET_E_DTYPE, "magnet_cost_volume_f_backward: fp32 features required");
+    if (!grad_cost || !grad_ref_cl || !grad_src_pad) return fail(MAGNET_E_NULL, "magnet_cost_volume_f_backward: NULL gradient pointer");
+    if (!aligned16(grad_ref_cl) || !aligned16(grad_src_pad))
+        return fail(MAGNET_E_ALIGN, "magnet_cost_volume_f_backward: gradient buffers must be 16-byte aligned");
+    bool handled = false;
+    hipError_t e = magnet::launch_cvf_bwd(p, grad_cost, grad_ref_cl, grad_src_pad, (hipStream_t)stream, &handled);
+    if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_f_backward launch");
+    if (!handled) return fail(MAGNET_E_DIM, "magnet_cost_volume_f_backward: shape not supported (F > 128, V > 31 or image too large)");
     return 0;
 }
 

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void cv_generic_kernel(const CvParams p) {
     const float r1 = p.rays[((size_t)b * 3 + 1) * hw + pix];
     const float r2 = p.rays[((size_t)b * 3 + 2) * hw + pix];
     float mu = 0.f, sg = 0.f;
-    if (!p.d_volume) {
+    if (!p.d_volume && !p.mode_f) {
         mu = p.ref_gmm[((size_t)b * 2 + 0) * hw + pix];
         sg = p.ref_gmm[((size_t)b * 2 + 1) * hw + pix];
     }
@@ -79,8 +79,10 @@ __global__ __launch_bounds__(256) void cv_generic_kernel(const CvParams p) {
         if (j >= p.D) break;                                       // wave-uniform
         float d;
         if (p.d_volume) d = p.d_volume[((size_t)b * p.D + j) * hw + pix];
+        else if (p.mode_f) d = p.k[j];                             // est_costvolume_F: fixed depth bins
         else { const float sk = sg * p.k[j]; d = mu + sk; }        // MAGNET.py:155 (mul, then add)
         double acc = 0.0;
+        float accf = 0.f;                                          // mode 1: fp32 view sum (homography.py:42)
 #pragma unroll 1
         for (int v = 0; v < p.V; ++v) {
             if (p.is_valid[b * p.V + v] != 1) continue;            // homography.py:97 (wave-uniform)
@@ -121,13 +123,16 @@ __global__ __launch_bounds__(256) void cv_generic_kernel(const CvParams p) {
                     }
                 }
                 c = (lvl0 + lvl1) + lvl2;
-                mu_w = bilerp(sgm[o_nw * 2], sgm[o_ne * 2], sgm[o_sw * 2], sgm[o_se * 2], t);
-                sg_w = bilerp(sgm[o_nw * 2 + 1], sgm[o_ne * 2 + 1], sgm[o_sw * 2 + 1], sgm[o_se * 2 + 1], t);
+                if (!p.mode_f) {
+                    mu_w = bilerp(sgm[o_nw * 2], sgm[o_ne * 2], sgm[o_sw * 2], sgm[o_se * 2], t);
+                    sg_w = bilerp(sgm[o_nw * 2 + 1], sgm[o_ne * 2 + 1], sgm[o_sw * 2 + 1], sgm[o_se * 2 + 1], t);
+                }
             }
             const bool gate = __builtin_fabsf(zw - mu_w) < sg_w * p.kappa;   // homography.py:157-158
-            acc += (double)c * (gate ? 1.0 : 0.0);                           // fp64 view sum, :159,116
+            if (p.mode_f) accf = accf + c;                                   // no gate, fp32 sum (homography.py:42)
+            else acc += (double)c * (gate ? 1.0 : 0.0);                      // fp64 view sum, :159,116
         }
-        if (inb) p.cost[(size_t)b * p.cost_bstride + (size_t)j * hw + pix] = (float)acc / fV;   // :118,120
+        if (inb) p.cost[(size_t)b * p.cost_bstride + (size_t)j * hw + pix] = (p.mode_f ? accf : (float)acc) / fV;   // :46 / :118,120
     }
     if (p.stats && tid == 0) atomicAdd(p.stats + 1, 1u);
 }

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
             }
             float d;
             if (p.d_volume) d = p.d_volume[((size_t)b * p.D + jc) * hw + pix];
+            else if (p.mode_f) d = kj;                                            // fixed depth bin (homography.py:54)
             else {
                 const float mu = p.ref_gmm[((size_t)b * 2 + 0) * hw + pix];
                 const float sg = p.ref_gmm[((size_t)b * 2 + 1) * hw + pix];
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
             }
             d = live ? d : __builtin_nanf("");                                    // dead lane -> out of image below
             double acc = 0.0;
+            float accf = 0.f;                                                     // mode 1: fp32 view sum (homography.py:42)
 
             for (int v = 0; v < p.V; ++v) {
                 if (!((vmask >> v) & 1ull)) continue;                            // homography.py:97 (wave-uniform)
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)KEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);  // wave_shr:1
                 if (j0 == 0) tprev = KEY_CLOSED;                                  // first candidate of a pixel group
                 const bool lead = inwin && (tkey != tprev);
-                if (lead && !(p.ablate & 2)) {
+                if (lead && !(p.ablate & 2) && !p.mode_f) {
                     g0 = *reinterpret_cast<const CGmmPair*>(sgm + qi * 8u);
                     g1 = *reinterpret_cast<const CGmmPair*>(sgm + (qi + (uint32_t)Wp) * 8u);
                 }
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 bool gate = inwin && (__builtin_fabsf(zw - mu_w) < sg_w * p.kappa);   // homography.py:157-158
                 if (p.ablate & 2) gate = inwin && ((j0 & 3) != 0);                // dev: taps skipped, ~75 % open
                 if (p.ablate & 8) gate = false;                                   // dev: geometry only
+                if (p.mode_f) gate = inwin;                                       // est_costvolume_F has no gate
 
                 // ---------------- distinct open quads of the wave -> items ----------------
                 const uint32_t key = gate ? qi : KEY_CLOSED;
@@ -257,11 +260,11 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 if (gate) {
                     const float4 c4 = *reinterpret_cast<const float4*>(ctab + myitem * 4);
                     const float c = bilerp(c4.x, c4.y, c4.z, c4.w, t);
-                    acc += (double)c;                                             // homography.py:159,116
+                    if (p.mode_f) accf = accf + c; else acc += (double)c;         // homography.py:42 / :159,116
                 }
                 wave_lds_fence();                                                 // ctab/items are rewritten by the next view
             }
-            const float cval = (float)acc / fV;                                   // homography.py:118,120
+            const float cval = (p.mode_f ? accf : (float)acc) / fV;               // homography.py:46 / :118,120
             if (p.cost_hi) {
                 // split-bf16 channel-last output for the conv kernel: lanes = consecutive channels of one row
                 if (live) {

@@ -15,6 +15,7 @@ struct CvParams {
     int B, V, F, D, h, w;
     int tiles_x, tiles_y;
     int feat_bf16;
+    int mode_f;                       // 1 = est_costvolume_F semantics (fixed bins, no gate, fp32 view sum)
     int ablate;                       // dev-only timing ablations (path >> 8): 1 = skip P2 dots, 2 = skip gmm taps
     float kappa;
     const void*    ref_feat;
@@ -64,5 +65,7 @@ __device__ __forceinline__ void tile_of_block(const CvParams& p, int& tile, int&
 hipError_t launch_cv_generic(const CvParams& p, hipStream_t stream);
 hipError_t launch_cv_worklist(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cv_cand(const CvParams& p, hipStream_t stream, bool* handled);
+hipError_t launch_cvf_bwd(const CvParams& p, const float* gout, float* grad_ref, float* grad_src, hipStream_t stream,
+                          bool* handled);
 
 }  // namespace magnet

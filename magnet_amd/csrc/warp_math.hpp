@@ -2,8 +2,9 @@
 //
 // The arithmetic mirrors, operation for operation, what the reference's ATen/BLAS CPU path
 // rounds (and therefore what oracle/cost_volume_oracle.c restates):
-//   * 3-term dot products (K*R, K*t, (K*R)*ray, R*ray) = a0*b0, then two fused accumulations
-//     (reference: models/submodules/homography.py:99-102, sgemm)
+//   * 3-term dot products of matrix-matrix products (K*R, (K*R)*ray, R*ray) = a0*b0, then two fused
+//     accumulations (reference: models/submodules/homography.py:99-102, sgemm); the matrix-vector product K*t
+//     (sgemv) = plain products summed left to right, unfused
 //   * P = t_pix + r_pix*d, z_warp = t_z + r_z*d : separate multiply and add (homography.py:132,137)
 //   * P / (P_z + 1e-10) and (P - c)/c : IEEE divisions (homography.py:133,143-146)
 //   * clamp to [-10,10] (homography.py:147-148); unnormalise = fma(g+1, size/2, -0.5)
@@ -43,7 +44,8 @@ __device__ __forceinline__ PixelView make_pixel_view(const float* __restrict__ K
         kr[i * 3 + 0] = dot3(k0, k1, k2, R00, R10, R20);
         kr[i * 3 + 1] = dot3(k0, k1, k2, R01, R11, R21);
         kr[i * 3 + 2] = dot3(k0, k1, k2, R02, R12, R22);
-        const float kt = dot3(k0, k1, k2, t0, t1, t2);
+        // K*t is a matrix-VECTOR product in the reference (sgemv): plain products, left to right, unfused
+        const float kt = (k0 * t0 + k1 * t1) + k2 * t2;
         if (i == 0) pv.kt0 = kt; else if (i == 1) pv.kt1 = kt; else pv.kt2 = kt;
     }
     pv.rpx = dot3(kr[0], kr[1], kr[2], r0, r1, r2);

@@ -119,3 +119,46 @@ def est_costvolume_CW(d_volume, ref_feat, nghbr_feat, ref_gmms, nghbr_gmms,
     poses = _poses_from_Rt(R.detach().float(), t.detach().float())
     cv = CostVolumeCW(ref_feat, nghbr_feat, nghbr_gmms, poses, is_valid, cam_intrins, thres, feat_dtype)
     return cv(d_volume=d_volume)
+
+
+class _CostVolumeF(torch.autograd.Function):
+    """Raw (pre-softmax) feature-matching volume of est_costvolume_F with its hand-written backward
+    (cost_volume_f_bwd.hip).  Features are differentiable; bins, poses and intrinsics are data."""
+
+    @staticmethod
+    def forward(ctx, ref_feat, nghbr_feat, bins, poses, is_valid, intM, rays, path):
+        ref_cl = lib.pack_features(ref_feat.detach().float().contiguous(), lib.FEAT_F32, pad=0)
+        src_pad = lib.pack_features(nghbr_feat.detach().float().contiguous(), lib.FEAT_F32, pad=1)
+        ctx.bins = bins
+        ctx.save_for_backward(ref_cl, src_pad, poses, is_valid, intM, rays)
+        return lib.cost_volume_cw(ref_cl, src_pad, None, poses, is_valid, intM, rays, 0.0, k_list=bins,
+                                  path=path, mode=1)
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        ref_cl, src_pad, poses, is_valid, intM, rays = ctx.saved_tensors
+        g_ref_cl, g_src_pad = lib.cost_volume_f_backward(ref_cl, src_pad, poses, is_valid, intM, rays, ctx.bins,
+                                                         grad_cost.float().contiguous())
+        # channel-last -> NCHW (+ drop the gradient of the zero padding): layout plumbing, outside the hot loop
+        g_ref = g_ref_cl.permute(0, 3, 1, 2).contiguous()
+        g_src = g_src_pad[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).contiguous()
+        return g_ref, g_src, None, None, None, None, None, None
+
+
+def est_costvolume_F(d_center, ref_feat, nghbr_feat, R, t, is_valid, cam_intrins, path: int = 0):
+    """Drop-in for homography.est_costvolume_F (reference homography.py:10-46), the matching volume the
+    F-Net is trained through (MAGNET.py:197-200): differentiable w.r.t. ref_feat and nghbr_feat.
+
+    d_center (1,D,1,1) fixed depth bins (CPU or GPU tensor); ref_feat (B,F,h,w); nghbr_feat (V*B,F,h,w)
+    view-major; R (B,V,3,3); t (B,V,3); is_valid (B,V); cam_intrins dict.  Returns softmax over D of the
+    view-averaged feature correlation, (B,D,h,w) fp32.  path = 1 selects the bit-faithful generic kernel."""
+    if not ref_feat.is_cuda:
+        raise lib.MagnetError("est_costvolume_F: features must be on the GPU (no CPU fallback)")
+    dev = ref_feat.device
+    bins = [float(v) for v in d_center.detach().float().reshape(-1).cpu().tolist()]
+    poses = _poses_from_Rt(R.detach().float(), t.detach().float()).to(dev).contiguous()
+    iv = _valid_to_device(is_valid, dev)
+    intM = _to_device_cached(cam_intrins["intM"], dev, torch.float32, _INTRINS_CACHE)
+    rays = _to_device_cached(cam_intrins["unit_ray_array_2D"], dev, torch.float32, _INTRINS_CACHE)
+    raw = _CostVolumeF.apply(ref_feat, nghbr_feat, bins, poses, iv, intM, rays, path)
+    return torch.softmax(raw, dim=1)                                   # homography.py:45

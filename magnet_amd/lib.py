@@ -20,7 +20,8 @@ MAX_CANDIDATES = 256
 
 API_SYMBOLS = ("magnet_version", "magnet_last_error", "magnet_device_count", "magnet_pack_features",
                "magnet_pack_gmm",
-               "magnet_cost_volume_cw", "magnet_gaussian_update", "magnet_upsample_depth")
+               "magnet_cost_volume_cw", "magnet_cost_volume_f_backward", "magnet_gaussian_update",
+               "magnet_upsample_depth")
 
 
 class MagnetError(RuntimeError):
@@ -42,6 +43,7 @@ class MagnetCostVolumeArgs(ctypes.Structure):
         ("path", ctypes.c_int32), ("stats", ctypes.c_void_p),
         ("cost_batch_stride", ctypes.c_int64),
         ("cost_hi", ctypes.c_void_p), ("cost_lo", ctypes.c_void_p), ("cost_ld", ctypes.c_int64),
+        ("mode", ctypes.c_int32),
     ]
 
 
@@ -68,6 +70,8 @@ def load() -> ctypes.CDLL:
     lib.magnet_pack_gmm.argtypes = [P, P, I, I, I, P]
     lib.magnet_cost_volume_cw.restype = ctypes.c_int
     lib.magnet_cost_volume_cw.argtypes = [ctypes.POINTER(MagnetCostVolumeArgs), P]
+    lib.magnet_cost_volume_f_backward.restype = ctypes.c_int
+    lib.magnet_cost_volume_f_backward.argtypes = [ctypes.POINTER(MagnetCostVolumeArgs), P, P, P, P]
     lib.magnet_gaussian_update.restype = ctypes.c_int
     lib.magnet_gaussian_update.argtypes = [P, P, P, I, I, P]
     lib.magnet_upsample_depth.restype = ctypes.c_int
@@ -143,7 +147,8 @@ def pack_gmm(gmm_nchw: torch.Tensor, out: torch.Tensor | None = None):
 
 
 def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM, rays, kappa,
-                   ref_gmm=None, k_list=None, d_volume=None, out=None, path: int = 0, stats=None, out_split=None):
+                   ref_gmm=None, k_list=None, d_volume=None, out=None, path: int = 0, stats=None, out_split=None,
+                   mode: int = 0):
     """Launch the fused matching kernel.  All tensors on one GPU; see MagnetCostVolumeArgs.
 
     ref_feat_cl (B,h,w,F) from pack_features(pad=0); src_feat_pad (V*B,h+2,w+2,F) from
@@ -163,10 +168,14 @@ def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM
     a.kappa = float(kappa)
     a.feat_dtype = fe
     a.ref_feat_cl, a.src_feat_pad = r.data_ptr(), s.data_ptr()
-    g = _dev(src_gmm_pad, "src_gmm_pad", torch.float32)
-    if tuple(g.shape) != (V * B, h + 2, w + 2, 2):
-        raise MagnetError(f"src_gmm_pad shape {tuple(g.shape)}, expected {(V * B, h + 2, w + 2, 2)}")
-    a.src_gmm_pad = g.data_ptr()
+    a.mode = int(mode)
+    if mode == 1 and src_gmm_pad is None:
+        g = s                                                      # no (mu,sigma) maps in est_costvolume_F mode
+    else:
+        g = _dev(src_gmm_pad, "src_gmm_pad", torch.float32)
+        if tuple(g.shape) != (V * B, h + 2, w + 2, 2):
+            raise MagnetError(f"src_gmm_pad shape {tuple(g.shape)}, expected {(V * B, h + 2, w + 2, 2)}")
+        a.src_gmm_pad = g.data_ptr()
     keep = [r, s, g]
     kbuf = None
     if d_volume is not None:
@@ -176,14 +185,16 @@ def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM
         D = dv.shape[1]
         a.d_volume = dv.data_ptr(); keep.append(dv)
     else:
-        if ref_gmm is None or k_list is None:
-            raise MagnetError("need d_volume, or ref_gmm and k_list")
-        rg = _dev(ref_gmm, "ref_gmm", torch.float32)
-        if tuple(rg.shape) != (B, 2, h, w):
-            raise MagnetError(f"ref_gmm shape {tuple(rg.shape)}, expected {(B, 2, h, w)}")
+        if k_list is None or (ref_gmm is None and mode != 1):
+            raise MagnetError("need d_volume, or ref_gmm and k_list (mode 1: k_list = depth bins)")
         D = len(k_list)
         kbuf = (ctypes.c_double * D)(*[float(k) for k in k_list])
-        a.ref_gmm = rg.data_ptr(); a.k_list = ctypes.addressof(kbuf); keep.append(rg)
+        a.k_list = ctypes.addressof(kbuf)
+        if mode != 1:
+            rg = _dev(ref_gmm, "ref_gmm", torch.float32)
+            if tuple(rg.shape) != (B, 2, h, w):
+                raise MagnetError(f"ref_gmm shape {tuple(rg.shape)}, expected {(B, 2, h, w)}")
+            a.ref_gmm = rg.data_ptr(); keep.append(rg)
     a.D = D
     po = _dev(poses, "poses", torch.float32); iv = _dev(is_valid, "is_valid", torch.int32)
     K = _dev(intM, "intM", torch.float32); ry = _dev(rays, "rays", torch.float32)
@@ -219,6 +230,42 @@ def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM
     with torch.cuda.device(r.device):
         _check(load().magnet_cost_volume_cw(ctypes.byref(a), _stream(r)), "magnet_cost_volume_cw")
     return out
+
+
+def cost_volume_f_backward(ref_feat_cl, src_feat_pad, poses, is_valid, intM, rays, d_center, grad_cost):
+    """Gradients of the mode-1 volume (est_costvolume_F before its softmax) w.r.t. the two feature maps.
+
+    Same tensors as the forward call (fp32 features) + grad_cost (B,D,h,w).  Returns
+    (grad_ref_cl (B,h,w,F), grad_src_pad (V*B,h+2,w+2,F)), both fp32 channel-last."""
+    r = _dev(ref_feat_cl, "ref_feat_cl", torch.float32)
+    s = _dev(src_feat_pad, "src_feat_pad", torch.float32)
+    B, h, w, F = r.shape
+    if s.shape[0] % B != 0 or tuple(s.shape[1:]) != (h + 2, w + 2, F):
+        raise MagnetError(f"src_feat_pad shape {tuple(s.shape)} does not match ref_feat_cl {tuple(r.shape)}")
+    V = s.shape[0] // B
+    D = len(d_center)
+    g = _dev(grad_cost, "grad_cost", torch.float32)
+    if tuple(g.shape) != (B, D, h, w):
+        raise MagnetError(f"grad_cost shape {tuple(g.shape)}, expected {(B, D, h, w)}")
+    po = _dev(poses, "poses", torch.float32); iv = _dev(is_valid, "is_valid", torch.int32)
+    K = _dev(intM, "intM", torch.float32); ry = _dev(rays, "rays", torch.float32)
+    if tuple(po.shape) != (B, V, 4, 4) or tuple(iv.shape) != (B, V) or tuple(K.shape) != (B, 3, 3) \
+            or tuple(ry.shape) != (B, 3, h * w):
+        raise MagnetError("poses/is_valid/intM/rays shape mismatch")
+    a = MagnetCostVolumeArgs()
+    a.B, a.V, a.F, a.D, a.h, a.w = B, V, F, D, h, w
+    a.feat_dtype = FEAT_F32
+    a.mode = 1
+    a.ref_feat_cl, a.src_feat_pad = r.data_ptr(), s.data_ptr()
+    kbuf = (ctypes.c_double * D)(*[float(k) for k in d_center])
+    a.k_list = ctypes.addressof(kbuf)
+    a.poses, a.is_valid, a.intM, a.rays = po.data_ptr(), iv.data_ptr(), K.data_ptr(), ry.data_ptr()
+    grad_ref = torch.empty_like(r)
+    grad_src = torch.zeros_like(s)
+    with torch.cuda.device(r.device):
+        _check(load().magnet_cost_volume_f_backward(ctypes.byref(a), g.data_ptr(), grad_ref.data_ptr(),
+                                                    grad_src.data_ptr(), _stream(r)), "magnet_cost_volume_f_backward")
+    return grad_ref, grad_src
 
 
 def gaussian_update(gnet_out, gmm_in, out=None):

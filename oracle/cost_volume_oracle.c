@@ -17,7 +17,8 @@
  * CPU builds contract to FMA; those spots use explicit fmaf below:
  *
  *   d        = mu + sigma*(float)k_j                    MAGNET.py:155   (mul, then add)
- *   KR       = K*R, Kt = K*t                            homography.py:101-102 (sgemm: a0b0, then 2 fma)
+ *   KR       = K*R                                      homography.py:102 (sgemm: a0b0, then 2 fma)
+ *   Kt       = K*t                                      homography.py:101 (sgemv: plain l-to-r, unfused)
  *   r_pix    = KR*ray ; r_cam_z = (R*ray)_z             homography.py:100,102
  *   P        = t_pix + r_pix*d                          homography.py:132
  *   P       /= (P_z + 1e-10)                            homography.py:133   (no behind-camera test)
@@ -90,6 +91,12 @@ static inline float dot3(const float *a, float b0, float b1, float b2) {
     return __builtin_fmaf(a[2], b2, __builtin_fmaf(a[1], b1, a[0] * b0));
 }
 
+/* Matrix-VECTOR products (IntM.matmul(t), homography.py:27,101) go through sgemv, which rounds differently from
+ * sgemm: plain products summed left to right, no fusion (verified bitwise against torch 2.10 CPU on 3000 random K, t). */
+static inline float dot3_gemv(const float *a, float b0, float b1, float b2) {
+    return (a[0] * b0 + a[1] * b1) + a[2] * b2;
+}
+
 /*
  * d_volume: (B,D,h,w) candidate depths, or NULL to sample them in place from ref_gmm + k_list.
  * gates:    optional (B,V,D,h,w) uint8 output of the consistency gate bits (0 for invalid views).
@@ -139,7 +146,7 @@ ORACLE_API int magnet_oracle_cost_volume_cw(
                         for (int i = 0; i < 3; ++i) {
                             for (int c = 0; c < 3; ++c)
                                 KR[i * 3 + c] = dot3(K + i * 3, R[0 * 3 + c], R[1 * 3 + c], R[2 * 3 + c]);
-                            Kt[i] = dot3(K + i * 3, t[0], t[1], t[2]);
+                            Kt[i] = dot3_gemv(K + i * 3, t[0], t[1], t[2]);
                         }
                         const float rpx = dot3(KR + 0, ray0, ray1, ray2);
                         const float rpy = dot3(KR + 3, ray0, ray1, ray2);
@@ -181,6 +188,106 @@ ORACLE_API int magnet_oracle_cost_volume_cw(
                         acc += (double)c * (gate ? 1.0 : 0.0);
                     }
                     out[((size_t)b * D + j) * hw + p] = (float)acc / (float)V;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/*
+ * est_costvolume_F / _compute_cost_F (models/submodules/homography.py:10-75), BEFORE the final softmax:
+ * fixed depth bins d_center[j] shared by all pixels, no consistency gate, feature cost summed over valid views
+ * in FP32 (homography.py:42: ref_mv_cost = ref_mv_cost + cost, both fp32) and divided by ALL views (:46).
+ * Also returns, when the grad_* pointers are given, the gradients of  L = sum(gout * out)  with respect to the
+ * reference and source features (what autograd gives through grid_sample / mul / sum; double accumulation here,
+ * compared with a tolerance) — the checker of the HIP backward kernel.
+ */
+ORACLE_API int magnet_oracle_cost_volume_f(
+    const float *d_center, const float *ref_feat, const float *src_feat,
+    const float *poses, const int32_t *is_valid, const float *intM, const float *rays,
+    int B, int V, int F, int D, int h, int w,
+    float *out, const float *gout, double *grad_ref, double *grad_src, int n_threads)
+{
+    const size_t hw = (size_t)h * w;
+    const float cw = (float)((double)w / 2.0), ch = (float)((double)h / 2.0);
+    const float sw_ = (float)w / 2.0f, sh_ = (float)h / 2.0f;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    /* gradients are accumulated serially over pixels when requested (small test shapes only) */
+    const int want_grad = gout && grad_ref && grad_src;
+    #pragma omp parallel for collapse(2) schedule(dynamic, 4) if(!want_grad)
+    for (int b = 0; b < B; ++b) {
+        for (int y = 0; y < h; ++y) {
+            const float *K = intM + (size_t)b * 9;
+            for (int x = 0; x < w; ++x) {
+                const size_t p = (size_t)y * w + x;
+                const float ray0 = rays[((size_t)b * 3 + 0) * hw + p];
+                const float ray1 = rays[((size_t)b * 3 + 1) * hw + p];
+                const float ray2 = rays[((size_t)b * 3 + 2) * hw + p];
+                for (int j = 0; j < D; ++j) {
+                    const float d = d_center[j];
+                    float acc = 0.f;
+                    for (int v = 0; v < V; ++v) {
+                        if (is_valid[b * V + v] != 1) continue;
+                        const float *T = poses + ((size_t)b * V + v) * 16;
+                        float R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+                        float t[3] = {T[3], T[7], T[11]};
+                        float KR[9], Kt[3];
+                        for (int i = 0; i < 3; ++i) {
+                            for (int c = 0; c < 3; ++c)
+                                KR[i * 3 + c] = dot3(K + i * 3, R[0 * 3 + c], R[1 * 3 + c], R[2 * 3 + c]);
+                            Kt[i] = dot3_gemv(K + i * 3, t[0], t[1], t[2]);
+                        }
+                        const float rpx = dot3(KR + 0, ray0, ray1, ray2);
+                        const float rpy = dot3(KR + 3, ray0, ray1, ray2);
+                        const float rpz = dot3(KR + 6, ray0, ray1, ray2);
+                        float Px = Kt[0] + rpx * d;
+                        float Py = Kt[1] + rpy * d;
+                        float Pz = Kt[2] + rpz * d;
+                        const float zz = Pz + 1e-10f;
+                        Px = Px / zz; Py = Py / zz;
+                        float gx = (Px - cw) / cw, gy = (Py - ch) / ch;
+                        gx = clampf(gx, -10.f, 10.f); gy = clampf(gy, -10.f, 10.f);
+                        const float ix = __builtin_fmaf(gx + 1.0f, sw_, -0.5f);
+                        const float iy = __builtin_fmaf(gy + 1.0f, sh_, -0.5f);
+                        taps_t tp; make_taps(ix, iy, &tp);
+                        const size_t sidx = (size_t)v * B + b;
+                        const float *sf = src_feat + sidx * F * hw;
+                        const float *rf = ref_feat + (size_t)b * F * hw + p;
+                        float c = 0.f;
+                        const int inw = tp.finite && tp.x0 >= -1 && tp.x0 < w && tp.y0 >= -1 && tp.y0 < h;
+                        if (inw) {
+                            float lvl0 = 0.f, lvl1 = 0.f, lvl2 = 0.f;
+                            for (int f = 0; f < F; ++f) {
+                                float wv = bilinear(sf + (size_t)f * hw, h, w, &tp);
+                                float pr = rf[(size_t)f * hw] * wv;
+                                lvl0 = lvl0 + pr;
+                                if ((f & 15) == 15) { lvl1 = lvl1 + lvl0; lvl0 = 0.f;
+                                    if ((f & 255) == 255) { lvl2 = lvl2 + lvl1; lvl1 = 0.f; } }
+                            }
+                            c = (lvl0 + lvl1) + lvl2;
+                            if (want_grad) {
+                                const double g = (double)gout[((size_t)b * D + j) * hw + p] / (double)V;
+                                const int xs[4] = {tp.x0, tp.x0 + 1, tp.x0, tp.x0 + 1};
+                                const int ys[4] = {tp.y0, tp.y0, tp.y0 + 1, tp.y0 + 1};
+                                const float ws[4] = {tp.nw, tp.ne, tp.sw, tp.se};
+                                for (int f = 0; f < F; ++f) {
+                                    double warp = 0.0;
+                                    for (int k = 0; k < 4; ++k) {
+                                        if (ys[k] < 0 || ys[k] >= h || xs[k] < 0 || xs[k] >= w) continue;
+                                        const size_t o = (size_t)ys[k] * w + xs[k];
+                                        warp += (double)ws[k] * sf[(size_t)f * hw + o];
+                                        grad_src[(sidx * F + f) * hw + o] += g * ws[k] * rf[(size_t)f * hw];
+                                    }
+                                    grad_ref[((size_t)b * F + f) * hw + p] += g * warp;
+                                }
+                            }
+                        }
+                        acc = acc + c;
+                    }
+                    out[((size_t)b * D + j) * hw + p] = acc / (float)V;
                 }
             }
         }

@@ -42,6 +42,9 @@ def _lib():
         P = ctypes.c_void_p
         f.argtypes = [P] * 10 + [ctypes.c_int] * 6 + [ctypes.c_float] + [P] * 3 + [ctypes.c_int]
         _LIB.magnet_oracle_num_threads.restype = ctypes.c_int
+        ff = _LIB.magnet_oracle_cost_volume_f
+        ff.restype = ctypes.c_int
+        ff.argtypes = [P] * 7 + [ctypes.c_int] * 6 + [P] * 4 + [ctypes.c_int]
     return _LIB
 
 
@@ -128,6 +131,48 @@ def cost_volume_cw(d_volume, ref_gmm, k_list, ref_feat, src_feat, src_gmm, poses
         _ptr(out), _ptr(gates), _ptr(fc), int(n_threads))
     assert rc == 0
     return (out, gates, fc) if return_aux else out
+
+
+# ----------------------------------------------------------------------------------------------
+# N2  est_costvolume_F / _compute_cost_F  (models/submodules/homography.py:10-75) + gradients
+# ----------------------------------------------------------------------------------------------
+def cost_volume_f_raw(d_center, ref_feat, src_feat, poses, is_valid, intM, rays, gout=None, n_threads=0):
+    """Feature-matching cost volume BEFORE the softmax (homography.py:46): (B,D,h,w) fp32.  With `gout` (B,D,h,w)
+    also returns d(sum(gout*out))/d ref_feat and /d src_feat (float64) for the backward-kernel check."""
+    ref_feat = _f32(ref_feat); src_feat = _f32(src_feat); poses = _f32(poses); intM = _f32(intM); rays = _f32(rays)
+    dc = np.ascontiguousarray(np.asarray(d_center.detach().cpu().numpy() if hasattr(d_center, "detach") else d_center,
+                                         dtype=np.float32).reshape(-1))
+    B, F, h, w = ref_feat.shape
+    V = src_feat.shape[0] // B
+    D = dc.shape[0]
+    iv = np.ascontiguousarray(is_valid.detach().cpu().numpy() if hasattr(is_valid, "detach") else is_valid, dtype=np.int32)
+    out = np.empty((B, D, h, w), np.float32)
+    if gout is not None:
+        go = _f32(gout); gr = np.zeros(ref_feat.shape, np.float64); gs = np.zeros(src_feat.shape, np.float64)
+    else:
+        go = gr = gs = None
+    rc = _lib().magnet_oracle_cost_volume_f(_ptr(dc), _ptr(ref_feat), _ptr(src_feat), _ptr(poses), _ptr(iv), _ptr(intM),
+                                            _ptr(rays), B, V, F, D, h, w, _ptr(out), _ptr(go), _ptr(gr), _ptr(gs),
+                                            int(n_threads))
+    assert rc == 0
+    return (out, gr, gs) if gout is not None else out
+
+
+def softmax_dim1(x):
+    x = _f32(x)
+    e = np.exp(x - x.max(axis=1, keepdims=True))
+    return (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+
+
+def est_costvolume_F(d_center, ref_feat, nghbr_feat, R, t, is_valid, cam_intrins, n_threads=0):
+    """Reference signature (homography.py:10): softmax over D of the raw cost volume."""
+    ref_feat = _f32(ref_feat)
+    B = ref_feat.shape[0]; V = _f32(nghbr_feat).shape[0] // B
+    R = _f32(R).reshape(B, V, 3, 3); t = _f32(t).reshape(B, V, 3)
+    poses = np.zeros((B, V, 4, 4), np.float32)
+    poses[:, :, :3, :3] = R; poses[:, :, :3, 3] = t; poses[:, :, 3, 3] = 1
+    return softmax_dim1(cost_volume_f_raw(d_center, ref_feat, nghbr_feat, poses, is_valid, cam_intrins["intM"],
+                                          cam_intrins["unit_ray_array_2D"], n_threads=n_threads))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -245,6 +245,36 @@ def main():
     po, vo = oracle.relative_poses(exts[2].numpy(), [exts[i].numpy() for i in (0, 1, 3, 4)])
     print(f"[G8] oracle relative_poses: max|d|={np.abs(po - poses8.numpy()).max():.2e} valid equal={np.array_equal(vo, valid8.numpy())}")
 
+    # ---- G9 est_costvolume_F: forward (raw + softmax) and autograd gradients ---------------------------
+    wl9 = synth.Workload("g9", "scannet", 12, 16, V=3, D=10, F=8)
+    inp9 = synth.make_inputs(wl9, B=2, seed=9, invalid=[(0, 2)])
+    inp9["nghbr_poses"][1, 0, :3, 3] = torch.tensor([0.4, -0.3, -1.2])       # strong parallax / out-of-image samples
+    d_center = torch.tensor(np.exp(np.log(10.0 + 1 - 1e-3) * (np.arange(10) + 0.5) / 10) - (1 - 1e-3), dtype=torch.float32).view(1, 10, 1, 1)
+    rf = inp9["ref_feat"].clone().requires_grad_(True); sf = inp9["nghbr_feat"].clone().requires_grad_(True)
+    R9 = inp9["nghbr_poses"][:, :, :3, :3]; t9 = inp9["nghbr_poses"][:, :, :3, 3]
+    # instrumentation (not reference logic): expose the cost volume before the final softmax
+    _sm = ref_h.F.softmax
+    ref_h.F.softmax = lambda x, dim: x
+    try:
+        raw9 = ref_h.est_costvolume_F(d_center, rf, sf, R9, t9, inp9["is_valid"], inp9["cam_intrins"])
+    finally:
+        ref_h.F.softmax = _sm
+    gout9 = torch.randn(raw9.shape, generator=torch.Generator().manual_seed(91))
+    (raw9 * gout9).sum().backward()
+    with torch.no_grad():
+        soft9 = ref_h.est_costvolume_F(d_center, rf, sf, R9, t9, inp9["is_valid"], inp9["cam_intrins"])
+    out["G9_d_center"] = d_center.numpy(); out["G9_ref_feat"] = inp9["ref_feat"].numpy(); out["G9_nghbr_feat"] = inp9["nghbr_feat"].numpy()
+    out["G9_poses"] = inp9["nghbr_poses"].numpy(); out["G9_is_valid"] = inp9["is_valid"].numpy()
+    out["G9_intM"] = inp9["cam_intrins"]["intM"].numpy(); out["G9_rays"] = inp9["cam_intrins"]["unit_ray_array_2D"].numpy()
+    out["G9_raw"] = raw9.detach().numpy(); out["G9_softmax"] = soft9.numpy(); out["G9_gout"] = gout9.numpy()
+    out["G9_grad_ref"] = rf.grad.numpy(); out["G9_grad_src"] = sf.grad.numpy()
+    o_raw, o_gr, o_gs = oracle.cost_volume_f_raw(d_center, inp9["ref_feat"], inp9["nghbr_feat"], inp9["nghbr_poses"], inp9["is_valid"],
+                                                 inp9["cam_intrins"]["intM"], inp9["cam_intrins"]["unit_ray_array_2D"], gout=gout9)
+    print(f"[G9] oracle est_costvolume_F raw bitwise: {np.array_equal(o_raw, raw9.detach().numpy())} "
+          f"(max|d|={np.abs(o_raw - raw9.detach().numpy()).max():.2e}); softmax max|d|="
+          f"{np.abs(oracle.softmax_dim1(o_raw) - soft9.numpy()).max():.2e}; grad_ref max|d|={np.abs(o_gr - rf.grad.numpy()).max():.2e} "
+          f"grad_src max|d|={np.abs(o_gs - sf.grad.numpy()).max():.2e} (|grad| max {rf.grad.abs().max():.2f}/{sf.grad.abs().max():.2f})")
+
     path = os.path.join(HERE, "golden_v1.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB, {len(out)} arrays")

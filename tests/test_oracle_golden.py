@@ -124,3 +124,33 @@ def test_G8_relative_poses(golden):
     assert np.array_equal(valid, golden["G8_valid"])
     np.testing.assert_allclose(poses, golden["G8_poses"], rtol=0, atol=1e-6)
     assert valid[2].sum() == 0 and valid[1, 0] == 0      # NaN reference / NaN neighbour
+
+
+# ---- G9: est_costvolume_F (F-Net training volume) and its autograd gradients -------------------------
+def _g9(g):
+    return (g["G9_d_center"], g["G9_ref_feat"], g["G9_nghbr_feat"], g["G9_poses"], g["G9_is_valid"], g["G9_intM"], g["G9_rays"])
+
+
+def test_G9_costvolume_F_raw_bitwise(golden):
+    """B=2,V=3,F=8,12x16,D=10 incl. an invalid view and a strong-parallax pose: the volume before the softmax."""
+    raw = oracle.cost_volume_f_raw(*_g9(golden))
+    assert np.array_equal(raw, golden["G9_raw"])
+
+
+def test_G9_costvolume_F_softmax(golden):
+    p = golden["G9_poses"]
+    cam = {"intM": golden["G9_intM"], "unit_ray_array_2D": golden["G9_rays"]}
+    sm = oracle.est_costvolume_F(golden["G9_d_center"], golden["G9_ref_feat"], golden["G9_nghbr_feat"],
+                                 p[:, :, :3, :3], p[:, :, :3, 3], golden["G9_is_valid"], cam)
+    np.testing.assert_allclose(sm, golden["G9_softmax"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(sm.sum(axis=1), 1.0, atol=1e-6)
+
+
+def test_G9_costvolume_F_gradients(golden):
+    """The oracle's analytic fp64 gradients against the reference's autograd (fp32) on the same upstream gradient."""
+    _, gr, gs = oracle.cost_volume_f_raw(*_g9(golden), gout=golden["G9_gout"])
+    np.testing.assert_allclose(gr, golden["G9_grad_ref"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(gs, golden["G9_grad_src"], rtol=1e-5, atol=2e-6)
+    # invalid view (frame 0, view 2) receives exactly zero gradient
+    B = golden["G9_ref_feat"].shape[0]
+    assert not gs[2 * B + 0].any() and not golden["G9_grad_src"][2 * B + 0].any()
