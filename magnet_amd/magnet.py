@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import lib
 from .convnet import ConvStackMFMA
-from .homography import CostVolumeCW
+from .homography import CostVolumeCW, est_costvolume_F
 
 
 def depth_sampling(sampling_range, n_samples) -> list:
@@ -228,3 +228,22 @@ class MAGNET(nn.Module):
             nghbr_feat_4 = feat_4[B:, ...]
         return self.match_and_refine(ref_gmms, x_d3, ref_feat_4, nghbr_feat_4, nghbr_gmms, nghbr_poses,
                                      is_valid, cam_intrins, mode)
+
+
+class MAGNET_F(nn.Module):
+    """Mirror of the reference's F-Net training wrapper (models/MAGNET.py:179-202): F-Net features of the reference
+    and source images -> est_costvolume_F (softmax over D fixed depth bins of the view-averaged feature correlation).
+    The volume and its gradient w.r.t. the features run in hand-written HIP (magnet_amd.homography.est_costvolume_F);
+    `f_net` is the caller's module (the reference's FNET; backbones are out of scope here) and trains through it."""
+
+    def __init__(self, args, f_net: nn.Module):
+        super().__init__()
+        self.f_net = f_net
+
+    def forward(self, ref_img, nghbr_imgs, nghbr_poses, is_valid, cam_intrins, d_center):
+        B = ref_img.shape[0]
+        feat_4 = self.f_net(torch.cat((ref_img, nghbr_imgs), dim=0))            # MAGNET.py:188
+        ref_feat_4, nghbr_feat_4 = feat_4[:B], feat_4[B:]
+        Rs_src = nghbr_poses[:, :, :3, :3]                                       # MAGNET.py:193-194
+        ts_src = nghbr_poses[:, :, :3, 3]
+        return est_costvolume_F(d_center, ref_feat_4, nghbr_feat_4, Rs_src, ts_src, is_valid, cam_intrins)
