@@ -142,7 +142,9 @@ MAGNET_API int magnet_upsample_depth(const float *depth, const float *mask, floa
  * offset dy*(w+2)+dx.  Border rows of the output hold unspecified finite values: read interior rows only.
  * Weights: two bf16 planes of [taps][cout_pad][cin] (cin contiguous) — magnet_amd/convnet.py prepacks them
  * from nn.Conv2d's [cout][cin][kh][kw]; bias fp32 [cout_pad] (zero in the padding).
- * Limits: cin % 32 == 0; taps in {1, 9}; cout_pad a multiple of 128, or 144, or 16. */
+ * Limits: cin % 32 == 0; taps in {1, 4, 9}; cout_pad a multiple of 128, or 144, 64, 32, 16.
+ * The same kernel runs the F-Net (PSMNet feature extractor, models/submodules/F_psmnet.py:37-124) — see the fields
+ * after `addend_ld` (all zero = the behaviour described above). */
 typedef struct MagnetConvArgs {
     const void  *in_hi, *in_lo;            /* bf16 (rows, cin) */
     const void  *w_hi, *w_lo;              /* bf16 (taps, cout_pad, cin) */
@@ -158,9 +160,51 @@ typedef struct MagnetConvArgs {
                                               Used to hoist the loop-invariant x_d3 part of G-Net's first layer out of
                                               the refinement loop (models/MAGNET.py:151-168): W*[cost|x_d3] = Wc*cost + Wx*x_d3 */
     int32_t      addend_ld;                /* row pitch of addend (0 = cout_pad) */
-} MagnetConvArgs;
+    int32_t      dil;                      /* taps = 9: dilation (0 or 1 = none); the grid's border must be >= dil wide
+                                              (F_psmnet.py:47 layer4).  taps = 4: the 2x2 window (-1,-1),(-1,0),(0,-1),(0,0)
+                                              of a space-to-depth tensor = a stride-2 3x3 convolution (F_psmnet.py:40,45) */
+    int32_t      out_ld;                   /* elements between output rows (0 = cout_pad): write a channel slice of a wider
+                                              buffer in place (the 320-channel concatenation, F_psmnet.py:122) */
+    const void  *add_hi, *add_lo;          /* optional split-bf16 (rows, add_ld) residual input added before bias / ReLU
+                                              (BasicBlock `out += x`, F_psmnet.py:27-33) */
+    int32_t      add_ld;
+    int32_t      border_hp;                /* > 0: rows are positions of (image, border_hp, wp) grids with a `border_pad`-wide
+                                              border; outputs at border positions are written as ZEROS (they are the next
+                                              layer's zero padding) */
+    int32_t      border_pad;
+    int32_t      repad;                    /* > 0 (needs border_hp): only interior positions are written, re-addressed into
+                                              grids with a (repad-1)-wide border: hands the last layer's output to the
+                                              matcher's layouts (border 0 = reference features, 1 = source features) */
+} MagnetConvArgs;                          /* out_mode 2: one bf16 plane (round-to-nearest-even) at out_hi */
 
 MAGNET_API int magnet_conv_mfma(const MagnetConvArgs *args, void *stream);
+
+/* ---- the F-Net's non-GEMM layers (PSMNet feature extractor, models/submodules/F_psmnet.py:37-124; row N3) ----
+ * Activations are conv_mfma's format: zero-bordered channel-last grids as two bf16 planes (hi, lo). */
+
+/* firstconv[0] (F_psmnet.py:40): 3x3 stride-2 pad-1 convolution 3 -> 32 channels of the NCHW fp32 image (N,3,H,W) with the
+ * BatchNorm folded into wgt (32,3,3,3) / bias (32), then ReLU -> planes (N, H2+2, W2+2, 32), border 1 (interior written),
+ * H2 = (H-1)/2+1, W2 = (W-1)/2+1. */
+MAGNET_API int magnet_fnet_stem(const float *img, const float *wgt, const float *bias, void *out_hi, void *out_lo,
+                                int32_t N, int32_t H, int32_t W, void *stream);
+
+/* (N, H2+2, W2+2, C) border 1 -> (N, H4+2*opad, W4+2*opad, 4*C) border opad, channel (py*2+px)*C + c = in[2y+py, 2x+px, c]
+ * (zero where 2y+py >= H2 or 2x+px >= W2); H4 = (H2-1)/2+1.  With it the stride-2 convolutions of layer2[0]
+ * (F_psmnet.py:45,89-93) are stride-1 GEMMs: 3x3/s2 = conv_mfma taps=4 over 4*C channels, 1x1/s2 = taps=1 on phase 0.
+ * C % 8 == 0; interior written only. */
+MAGNET_API int magnet_space_to_depth(const void *in_hi, const void *in_lo, void *out_hi, void *out_lo, int32_t N, int32_t C,
+                                     int32_t H2, int32_t W2, int32_t opad, void *stream);
+
+/* AvgPool2d((k,k), stride (k,k)) (F_psmnet.py:50-64) of channels [0,C) at in_hi/in_lo (row pitch ld elements) of an
+ * (N, h+2*pad, w+2*pad) grid -> planes (N*(h/k)*(w/k), C).  C <= 128, C % 8 == 0. */
+MAGNET_API int magnet_avgpool_cl(const void *in_hi, const void *in_lo, int32_t ld, int32_t N, int32_t h, int32_t w, int32_t pad,
+                                 int32_t k, int32_t C, void *out_hi, void *out_lo, void *stream);
+
+/* F.interpolate(..., mode='bilinear', align_corners=True) (F_psmnet.py:108-119): fp32 (N*ph*pw, in_ld) -> planes, channels
+ * [0,C) at out_hi/out_lo (row pitch out_ld) of an (N, h+2*pad, w+2*pad) grid, interior only.  C % 8 == 0. */
+MAGNET_API int magnet_upsample_bilinear_cl(const float *in, int32_t in_ld, int32_t ph, int32_t pw, int32_t C, void *out_hi,
+                                           void *out_lo, int32_t out_ld, int32_t N, int32_t h, int32_t w, int32_t pad,
+                                           void *stream);
 
 /* The 1x1 tail of a stack in one launch: relu(conv1x1 128->128), relu(conv1x1 128->128), conv1x1 128->cout_pad.
  * in: split-bf16 (rows,128) planes (the 3x3 layer's out_mode-0 output); w_hi/w_lo: the three layers' [cout][128]

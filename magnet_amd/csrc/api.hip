@@ -5,37 +5,20 @@
 #include <stdio.h>
 #include <string.h>
 #include "cv_common.hpp"
+#include "conv_common.hpp"
 
 namespace magnet {
 hipError_t launch_pack(const float*, void*, int, int, int, int, bool, int, hipStream_t);
 hipError_t launch_pack_gmm(const float*, float*, int, int, int, hipStream_t);
 hipError_t launch_gaussian_update(const float*, const float*, float*, int, int, hipStream_t);
 hipError_t launch_upsample(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
-struct ConvParams {
-    const uint16_t* in_hi;  const uint16_t* in_lo;
-    const uint16_t* w_hi;   const uint16_t* w_lo;
-    const float*    bias;
-    uint16_t* out_hi; uint16_t* out_lo;
-    float*    out_f32;
-    long long rows;
-    int cin, cout_pad, taps, wp, relu, out_mode;
-    int in_ld;
-    const float* addend;
-    int addend_ld;
-};
-hipError_t launch_conv_mfma(const ConvParams&, hipStream_t);
-struct ChainParams {
-    const uint16_t* in_hi;  const uint16_t* in_lo;
-    const uint16_t* w_hi;   const uint16_t* w_lo;
-    const float*    bias;
-    float*          out;
-    long long rows;
-    int cout_pad;
-};
-hipError_t launch_conv1x1_chain(const ChainParams&, hipStream_t);
 hipError_t launch_pack_split(const float*, uint16_t*, uint16_t*, int, int, int, int, int, int, long long, hipStream_t);
 hipError_t launch_gaussian_update_cl(const float*, int, const float*, float*, int, int, int, hipStream_t);
 hipError_t launch_upsample_cl(const float*, const float*, int, float*, int, int, int, hipStream_t);
+hipError_t launch_fnet_stem(const float*, const float*, const float*, uint16_t*, uint16_t*, int, int, int, hipStream_t);
+hipError_t launch_space_to_depth(const uint16_t*, const uint16_t*, uint16_t*, uint16_t*, int, int, int, int, int, hipStream_t);
+hipError_t launch_avgpool_cl(const uint16_t*, const uint16_t*, int, int, int, int, int, int, int, uint16_t*, uint16_t*, hipStream_t);
+hipError_t launch_upsample_bilinear_cl(const float*, int, int, int, int, uint16_t*, uint16_t*, int, int, int, int, int, hipStream_t);
 hipError_t launch_depth_metrics(const float*, const float*, double*, int, int, float, float, hipStream_t);
 }
 
@@ -208,17 +191,20 @@ MAGNET_API int magnet_upsample_depth(const float* depth, const float* mask, floa
 MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     if (!a) return fail(MAGNET_E_NULL, "magnet_conv_mfma: args is NULL");
     if (!a->in_hi || !a->in_lo || !a->w_hi || !a->w_lo || !a->bias) return fail(MAGNET_E_NULL, "magnet_conv_mfma: NULL input pointer");
-    if (a->out_mode == 0 ? (!a->out_hi || !a->out_lo) : !a->out_f32) return fail(MAGNET_E_NULL, "magnet_conv_mfma: NULL output pointer");
-    if (a->out_mode != 0 && a->out_mode != 1) return fail(MAGNET_E_DIM, "magnet_conv_mfma: out_mode must be 0 or 1");
+    if (a->out_mode < 0 || a->out_mode > 2) return fail(MAGNET_E_DIM, "magnet_conv_mfma: out_mode must be 0, 1 or 2");
+    if (a->out_mode == 0 ? (!a->out_hi || !a->out_lo) : (a->out_mode == 1 ? !a->out_f32 : !a->out_hi))
+        return fail(MAGNET_E_NULL, "magnet_conv_mfma: NULL output pointer");
     if (a->rows <= 0 || a->cin <= 0 || (a->cin % 32) != 0) return fail(MAGNET_E_DIM, "magnet_conv_mfma: rows > 0 and cin %% 32 == 0 required (cin=%d)", a->cin);
-    if (a->taps != 1 && a->taps != 9) return fail(MAGNET_E_DIM, "magnet_conv_mfma: taps must be 1 or 9");
-    if (a->taps == 9 && a->wp < 3) return fail(MAGNET_E_DIM, "magnet_conv_mfma: wp (= w + 2) missing");
-    if (!((a->cout_pad > 0 && a->cout_pad % 128 == 0) || a->cout_pad == 144 || a->cout_pad == 16))
-        return fail(MAGNET_E_DIM, "magnet_conv_mfma: cout_pad=%d unsupported (multiple of 128, 144 or 16)", a->cout_pad);
+    if (a->taps != 1 && a->taps != 4 && a->taps != 9) return fail(MAGNET_E_DIM, "magnet_conv_mfma: taps must be 1, 4 or 9");
+    if (a->taps != 1 && a->wp < 3) return fail(MAGNET_E_DIM, "magnet_conv_mfma: wp (row pitch of the bordered grid) missing");
+    if (!((a->cout_pad > 0 && a->cout_pad % 128 == 0) || a->cout_pad == 144 || a->cout_pad == 16 || a->cout_pad == 32 || a->cout_pad == 64))
+        return fail(MAGNET_E_DIM, "magnet_conv_mfma: cout_pad=%d unsupported (multiple of 128, or 144, 64, 32, 16)", a->cout_pad);
     if (!aligned16(a->in_hi) || !aligned16(a->in_lo) || !aligned16(a->w_hi) || !aligned16(a->w_lo) ||
-        (a->out_mode == 0 ? (!aligned16(a->out_hi) || !aligned16(a->out_lo)) : !aligned16(a->out_f32)))
+        (a->out_mode == 0 ? (!aligned16(a->out_hi) || !aligned16(a->out_lo)) : (a->out_mode == 1 ? !aligned16(a->out_f32) : !aligned16(a->out_hi))))
         return fail(MAGNET_E_ALIGN, "magnet_conv_mfma: pointers must be 16-byte aligned");
+    if (a->dil < 0 || a->dil > 8) return fail(MAGNET_E_DIM, "magnet_conv_mfma: dil=%d out of range", a->dil);
     magnet::ConvParams p;
+    memset(&p, 0, sizeof(p));
     p.in_hi = (const uint16_t*)a->in_hi; p.in_lo = (const uint16_t*)a->in_lo;
     p.w_hi = (const uint16_t*)a->w_hi; p.w_lo = (const uint16_t*)a->w_lo; p.bias = a->bias;
     p.out_hi = (uint16_t*)a->out_hi; p.out_lo = (uint16_t*)a->out_lo; p.out_f32 = a->out_f32;
@@ -229,8 +215,69 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     if (a->addend && (!aligned16(a->addend) || (p.addend_ld % 4) != 0 || p.addend_ld < a->cout_pad))
         return fail(MAGNET_E_ALIGN, "magnet_conv_mfma: addend must be 16-byte aligned with addend_ld >= cout_pad, a multiple of 4");
     if (p.in_ld < a->cin || (p.in_ld % 8) != 0) return fail(MAGNET_E_DIM, "magnet_conv_mfma: in_ld=%d must be >= cin and a multiple of 8", p.in_ld);
+    const int dil = a->dil > 1 ? a->dil : 1;
+    if (a->taps == 9) for (int t = 0; t < 9; ++t) p.tap_off[t] = ((t / 3 - 1) * a->wp + (t % 3 - 1)) * dil;
+    if (a->taps == 4) { p.tap_off[0] = -a->wp - 1; p.tap_off[1] = -a->wp; p.tap_off[2] = -1; p.tap_off[3] = 0; }
+    p.out_ld = a->out_ld ? a->out_ld : a->cout_pad;
+    if (p.out_ld < a->cout_pad || (p.out_ld % 8) != 0) return fail(MAGNET_E_DIM, "magnet_conv_mfma: out_ld=%d must be >= cout_pad and a multiple of 8", p.out_ld);
+    p.add_hi = (const uint16_t*)a->add_hi; p.add_lo = (const uint16_t*)a->add_lo; p.add_ld = a->add_ld ? a->add_ld : a->cout_pad;
+    if ((a->add_hi != nullptr) != (a->add_lo != nullptr)) return fail(MAGNET_E_NULL, "magnet_conv_mfma: add_hi and add_lo come together");
+    if (a->add_hi && (!aligned16(a->add_hi) || !aligned16(a->add_lo) || (p.add_ld % 8) != 0 || p.add_ld < a->cout_pad))
+        return fail(MAGNET_E_ALIGN, "magnet_conv_mfma: add_hi/add_lo must be 16-byte aligned with add_ld >= cout_pad, a multiple of 8");
+    if (a->border_hp) {
+        if (a->wp < 1 || a->border_pad < 0 || a->border_hp <= 2 * a->border_pad || a->wp <= 2 * a->border_pad ||
+            (a->rows % ((long long)a->border_hp * a->wp)) != 0)
+            return fail(MAGNET_E_DIM, "magnet_conv_mfma: border_hp=%d wp=%d border_pad=%d do not tile rows=%lld", a->border_hp, a->wp, a->border_pad, (long long)a->rows);
+        p.img_rows = a->border_hp * a->wp; p.hp = a->border_hp; p.pad = a->border_pad;
+    }
+    if (a->repad < 0 || (a->repad && !a->border_hp)) return fail(MAGNET_E_DIM, "magnet_conv_mfma: repad needs border_hp");
+    p.repad = a->repad;
     hipError_t e = magnet::launch_conv_mfma(p, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_conv_mfma launch");
+}
+
+MAGNET_API int magnet_fnet_stem(const float* img, const float* wgt, const float* bias, void* out_hi, void* out_lo, int32_t N,
+                                int32_t H, int32_t W, void* stream) {
+    if (!img || !wgt || !bias || !out_hi || !out_lo) return fail(MAGNET_E_NULL, "magnet_fnet_stem: NULL pointer");
+    if (N <= 0 || H < 2 || W < 2) return fail(MAGNET_E_DIM, "magnet_fnet_stem: bad dims N=%d H=%d W=%d", N, H, W);
+    if (!aligned16(out_hi) || !aligned16(out_lo)) return fail(MAGNET_E_ALIGN, "magnet_fnet_stem: outputs must be 16-byte aligned");
+    hipError_t e = magnet::launch_fnet_stem(img, wgt, bias, (uint16_t*)out_hi, (uint16_t*)out_lo, N, H, W, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_fnet_stem launch");
+}
+
+MAGNET_API int magnet_space_to_depth(const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int32_t N, int32_t C,
+                                     int32_t H2, int32_t W2, int32_t opad, void* stream) {
+    if (!in_hi || !in_lo || !out_hi || !out_lo) return fail(MAGNET_E_NULL, "magnet_space_to_depth: NULL pointer");
+    if (N <= 0 || C <= 0 || (C % 8) != 0 || H2 <= 0 || W2 <= 0 || opad < 0)
+        return fail(MAGNET_E_DIM, "magnet_space_to_depth: bad dims N=%d C=%d H2=%d W2=%d opad=%d", N, C, H2, W2, opad);
+    if (!aligned16(in_hi) || !aligned16(in_lo) || !aligned16(out_hi) || !aligned16(out_lo))
+        return fail(MAGNET_E_ALIGN, "magnet_space_to_depth: pointers must be 16-byte aligned");
+    hipError_t e = magnet::launch_space_to_depth((const uint16_t*)in_hi, (const uint16_t*)in_lo, (uint16_t*)out_hi, (uint16_t*)out_lo,
+                                                 N, C, H2, W2, opad, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_space_to_depth launch");
+}
+
+MAGNET_API int magnet_avgpool_cl(const void* in_hi, const void* in_lo, int32_t ld, int32_t N, int32_t h, int32_t w, int32_t pad,
+                                 int32_t k, int32_t C, void* out_hi, void* out_lo, void* stream) {
+    if (!in_hi || !in_lo || !out_hi || !out_lo) return fail(MAGNET_E_NULL, "magnet_avgpool_cl: NULL pointer");
+    if (N <= 0 || C <= 0 || C > 128 || (C % 8) != 0 || ld < C || (ld % 8) != 0 || k <= 0 || h < k || w < k || pad < 0)
+        return fail(MAGNET_E_DIM, "magnet_avgpool_cl: bad dims N=%d C=%d ld=%d h=%d w=%d k=%d pad=%d", N, C, ld, h, w, k, pad);
+    if (!aligned16(in_hi) || !aligned16(in_lo) || !aligned16(out_hi) || !aligned16(out_lo))
+        return fail(MAGNET_E_ALIGN, "magnet_avgpool_cl: pointers must be 16-byte aligned");
+    hipError_t e = magnet::launch_avgpool_cl((const uint16_t*)in_hi, (const uint16_t*)in_lo, ld, N, h, w, pad, k, C, (uint16_t*)out_hi,
+                                             (uint16_t*)out_lo, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_avgpool_cl launch");
+}
+
+MAGNET_API int magnet_upsample_bilinear_cl(const float* in, int32_t in_ld, int32_t ph, int32_t pw, int32_t C, void* out_hi,
+                                           void* out_lo, int32_t out_ld, int32_t N, int32_t h, int32_t w, int32_t pad, void* stream) {
+    if (!in || !out_hi || !out_lo) return fail(MAGNET_E_NULL, "magnet_upsample_bilinear_cl: NULL pointer");
+    if (N <= 0 || C <= 0 || (C % 8) != 0 || in_ld < C || out_ld < C || (out_ld % 8) != 0 || ph <= 0 || pw <= 0 || h <= 0 || w <= 0 || pad < 0)
+        return fail(MAGNET_E_DIM, "magnet_upsample_bilinear_cl: bad dims");
+    if (!aligned16(out_hi) || !aligned16(out_lo)) return fail(MAGNET_E_ALIGN, "magnet_upsample_bilinear_cl: outputs must be 16-byte aligned");
+    hipError_t e = magnet::launch_upsample_bilinear_cl(in, in_ld, ph, pw, C, (uint16_t*)out_hi, (uint16_t*)out_lo, out_ld, N, h, w, pad,
+                                                       (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_upsample_bilinear_cl launch");
 }
 
 MAGNET_API int magnet_conv1x1_chain(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias,

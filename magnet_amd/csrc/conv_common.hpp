@@ -1,0 +1,40 @@
+// conv_common.hpp — launch parameters of the matrix-core convolution kernels (conv_mfma.hip), shared with api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace magnet {
+
+struct ConvParams {
+    const uint16_t* in_hi;  const uint16_t* in_lo;    // activations, row 0 of the flattened padded grid
+    const uint16_t* w_hi;   const uint16_t* w_lo;     // [taps][cout_pad][cin]
+    const float*    bias;                             // [cout_pad]
+    uint16_t* out_hi; uint16_t* out_lo;               // OUT mode 0: bf16 planes [rows][cout_pad]
+    float*    out_f32;                                // OUT mode 1: fp32 [rows][cout_pad]
+    long long rows;                                   // B*(h+2)*(w+2)
+    int cin, cout_pad, taps, wp, relu, out_mode;
+    int in_ld;                                        // elements between consecutive input rows (>= cin)
+    const float* addend;                              // optional fp32 (rows, addend_ld) added before bias/ReLU
+    int addend_ld;
+    int tap_off[9];                                   // input row offset of each tap (dilation / 2x2 windows: host-computed)
+    int out_ld;                                       // elements between consecutive output rows (>= cout_pad)
+    const uint16_t* add_hi; const uint16_t* add_lo;   // optional split-bf16 addend (residual connections), rows x add_ld
+    int add_ld;
+    int img_rows, hp, pad;                            // img_rows = hp*wp > 0: rows are decoded to (image, y, x) and outputs of
+                                                      // the `pad`-wide border are written as zeros (next layer's zero padding)
+    int repad;                                        // > 0: interior rows only, re-addressed to a grid with border repad-1
+};
+
+struct ChainParams {
+    const uint16_t* in_hi;  const uint16_t* in_lo;    // (rows, 128)
+    const uint16_t* w_hi;   const uint16_t* w_lo;     // [128][128], [128][128], [cout_pad][128] concatenated
+    const float*    bias;                             // 128 + 128 + cout_pad
+    float*          out;                              // (rows, cout_pad) fp32
+    long long rows;
+    int cout_pad;
+};
+
+hipError_t launch_conv_mfma(const ConvParams&, hipStream_t);
+hipError_t launch_conv1x1_chain(const ChainParams&, hipStream_t);
+
+}  // namespace magnet

@@ -23,24 +23,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/magnet_hip.h"
+#include "conv_common.hpp"
 
 namespace magnet {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
-struct ConvParams {
-    const uint16_t* in_hi;  const uint16_t* in_lo;    // activations, row 0 of the flattened padded grid
-    const uint16_t* w_hi;   const uint16_t* w_lo;     // [taps][cout_pad][cin]
-    const float*    bias;                             // [cout_pad]
-    uint16_t* out_hi; uint16_t* out_lo;               // OUT mode 0: bf16 planes [rows][cout_pad]
-    float*    out_f32;                                // OUT mode 1: fp32 [rows][cout_pad]
-    long long rows;                                   // B*(h+2)*(w+2)
-    int cin, cout_pad, taps, wp, relu, out_mode;
-    int in_ld;                                        // elements between consecutive input rows (>= cin)
-    const float* addend;                              // optional fp32 (rows, addend_ld) added before bias/ReLU
-    int addend_ld;
-};
 
 constexpr int CV_BK = 32;
 constexpr int CV_ROW = 64;                            // bytes per staged row (32 bf16), unpadded
@@ -106,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     // swept 164 KB per workgroup between re-reads (x64 resident workgroups >> 4 MiB L2).
     auto a_elem = [&](int s, int i) -> size_t {
         const int tap = s % p.taps, k0 = (s / p.taps) * CV_BK;
-        const int off = (p.taps == 9) ? ((tap / 3 - 1) * p.wp + (tap % 3 - 1)) : 0;
+        const int off = p.tap_off[tap];
         long long row = row0 + st_r + i * 64 + off;
         row = row < 0 ? 0 : (row >= p.rows ? p.rows - 1 : row);        // guard rows only feed border outputs
         return (size_t)row * p.in_ld + k0 + st_k;
@@ -211,8 +199,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             const long long row = row0 + wm * (MF * 16) + m * 16 + r;
             if (row >= p.rows) continue;
             const int ch = n0 + wn * WCOLS + c8;
+            long long orow = row;
+            bool interior = true;
+            if (p.img_rows) {                                 // row -> (image, y, x) of the zero-bordered grid
+                const long long img = row / p.img_rows;
+                const int rem = (int)(row - img * p.img_rows);
+                const int y = rem / p.wp, x = rem - y * p.wp;
+                interior = (y >= p.pad) && (y < p.hp - p.pad) && (x >= p.pad) && (x < p.wp - p.pad);
+                if (p.repad) {
+                    if (!interior) continue;
+                    const int q = p.repad - 1, hh = p.hp - 2 * p.pad, ww = p.wp - 2 * p.pad;
+                    orow = (img * (hh + 2 * q) + (y - p.pad + q)) * (ww + 2 * q) + (x - p.pad + q);
+                }
+            }
             float v[8];
             float ad[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.add_hi) {                                   // residual input, stored as split bf16 planes
+                const uint4 ah = *reinterpret_cast<const uint4*>(p.add_hi + (size_t)row * p.add_ld + ch);
+                const uint4 al = *reinterpret_cast<const uint4*>(p.add_lo + (size_t)row * p.add_ld + ch);
+                const uint32_t hw_[4] = {ah.x, ah.y, ah.z, ah.w}, lw_[4] = {al.x, al.y, al.z, al.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ad[2 * i]     = __uint_as_float(hw_[i] << 16) + __uint_as_float(lw_[i] << 16);
+                    ad[2 * i + 1] = __uint_as_float(hw_[i] & 0xffff0000u) + __uint_as_float(lw_[i] & 0xffff0000u);
+                }
+            }
             if (p.addend) {                                   // loop-invariant partial sums computed once per forward
                 const float4 a0 = *reinterpret_cast<const float4*>(p.addend + (size_t)row * p.addend_ld + ch);
                 const float4 a1 = *reinterpret_cast<const float4*>(p.addend + (size_t)row * p.addend_ld + ch + 4);
@@ -222,9 +233,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             for (int i = 0; i < 8; ++i) {
                 float x = (stage[r * SROW + c8 + i] + ad[i]) + p.bias[ch + i];
                 v[i] = (p.relu && x < 0.f) ? 0.f : x;
+                if (!interior) v[i] = 0.f;
             }
-            const size_t e = (size_t)row * p.cout_pad + ch;
-            if (p.out_mode == 0) {
+            const size_t e = (size_t)orow * p.out_ld + ch;
+            if (p.out_mode == 2) {                            // single bf16 plane (RNE): the matcher's bf16 feature storage
+                uint32_t h[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = (uint32_t)bf16_rne(v[2 * i]) | ((uint32_t)bf16_rne(v[2 * i + 1]) << 16);
+                *reinterpret_cast<uint4*>(p.out_hi + e) = make_uint4(h[0], h[1], h[2], h[3]);
+            } else if (p.out_mode == 0) {
                 uint32_t h[4], l[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -272,6 +289,8 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
     if (p.cout_pad % 128 == 0) return launch_conv_nf<8, 2, 128, 1>(p, s);
     if (p.cout_pad == 144) return launch_conv_nf<9, 1, 128, 1>(p, s);
     if (p.cout_pad == 16)  return launch_conv_nf<1, 1, 128, 1>(p, s);
+    if (p.cout_pad == 32)  return launch_conv_nf<2, 1, 128, 1>(p, s);      // F-Net trunk widths: 4 waves stacked along M
+    if (p.cout_pad == 64)  return launch_conv_nf<4, 1, 128, 1>(p, s);
     return hipErrorInvalidValue;
 }
 
@@ -287,15 +306,6 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
 //     layers, 16-byte fp32 global stores for the last one;
 //   * activation tile rows are 256 B with slot ^= (row & 15) (conflict-free fragment reads); weight tiles are
 //     streamed per 32-wide K chunk through the same double-buffered swizzled image as conv_mfma_kernel.
-struct ChainParams {
-    const uint16_t* in_hi;  const uint16_t* in_lo;    // (rows, 128)
-    const uint16_t* w_hi;   const uint16_t* w_lo;     // [128][128], [128][128], [cout_pad][128] concatenated
-    const float*    bias;                             // 128 + 128 + cout_pad
-    float*          out;                              // (rows, cout_pad) fp32
-    long long rows;
-    int cout_pad;
-};
-
 __device__ __forceinline__ int act_swz(int row, int slot) { return row * 256 + ((slot ^ (row & 15)) << 4); }
 
 // one layer: acc[n][m] over K = 128 for this wave's 32 rows; NF = output fragments (channels / 16)

@@ -73,15 +73,24 @@ class CostVolumeCW:
     event_sink = None
 
     def __init__(self, ref_feat, nghbr_feat, nghbr_gmms, nghbr_poses, is_valid, cam_intrins, thres,
-                 feat_dtype="fp32", path: int = 0):
-        dev = ref_feat.device
-        if not ref_feat.is_cuda:
-            raise lib.MagnetError("CostVolumeCW: features must be on the GPU (no CPU fallback)")
-        self.fe = lib.feat_enum(feat_dtype)
-        self.B, self.F, self.h, self.w = ref_feat.shape
-        self.V = nghbr_feat.shape[0] // self.B
-        self.ref_cl = lib.pack_features(ref_feat.detach().float().contiguous(), self.fe, pad=0)
-        self.src_pad = lib.pack_features(nghbr_feat.detach().float().contiguous(), self.fe, pad=1)
+                 feat_dtype="fp32", path: int = 0, packed=None):
+        """packed = (ref_cl (B,h,w,F), src_pad (V*B,h+2,w+2,F)): features already in the kernel's layouts (the
+        matrix-core F-Net writes them directly, magnet_amd/fnet.py); ref_feat / nghbr_feat are then ignored."""
+        if packed is not None:
+            self.ref_cl, self.src_pad = packed
+            dev = self.ref_cl.device
+            self.fe = lib.feat_enum(self.ref_cl.dtype)
+            self.B, self.h, self.w, self.F = self.ref_cl.shape
+            self.V = self.src_pad.shape[0] // self.B
+        else:
+            dev = ref_feat.device
+            if not ref_feat.is_cuda:
+                raise lib.MagnetError("CostVolumeCW: features must be on the GPU (no CPU fallback)")
+            self.fe = lib.feat_enum(feat_dtype)
+            self.B, self.F, self.h, self.w = ref_feat.shape
+            self.V = nghbr_feat.shape[0] // self.B
+            self.ref_cl = lib.pack_features(ref_feat.detach().float().contiguous(), self.fe, pad=0)
+            self.src_pad = lib.pack_features(nghbr_feat.detach().float().contiguous(), self.fe, pad=1)
         self.src_gmm_pad = lib.pack_gmm(nghbr_gmms.detach().float().contiguous())
         self.poses = nghbr_poses.detach().to(device=dev, dtype=torch.float32).contiguous()
         self.is_valid = _valid_to_device(is_valid, dev)

@@ -308,6 +308,9 @@ class MagnetConvArgs(ctypes.Structure):
         ("cin", ctypes.c_int32), ("cout_pad", ctypes.c_int32), ("taps", ctypes.c_int32), ("wp", ctypes.c_int32),
         ("relu", ctypes.c_int32), ("out_mode", ctypes.c_int32), ("in_ld", ctypes.c_int32),
         ("addend", ctypes.c_void_p), ("addend_ld", ctypes.c_int32),
+        ("dil", ctypes.c_int32), ("out_ld", ctypes.c_int32),
+        ("add_hi", ctypes.c_void_p), ("add_lo", ctypes.c_void_p), ("add_ld", ctypes.c_int32),
+        ("border_hp", ctypes.c_int32), ("border_pad", ctypes.c_int32), ("repad", ctypes.c_int32),
     ]
 
 
@@ -331,10 +334,19 @@ def _conv_protos(lib):
     return lib
 
 
+def _bf16_ptr(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.bfloat16:
+        raise MagnetError(f"{name} must be a bf16 GPU tensor")
+    return t.data_ptr()
+
+
 def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, out_hi=None, out_lo=None, out_f32=None,
-              addend=None):
+              addend=None, dil=0, out_ld=0, add=None, border=None, repad=0, out_bf16=None):
     """One convolution layer on the matrix cores.  in_hi/in_lo: bf16 tensors whose data_ptr is row 0 (possibly a
-    channel-offset view of a wider buffer, `in_ld` = its row pitch in elements); weights (taps, cout_pad, cin) bf16."""
+    channel-offset view of a wider buffer, `in_ld` = its row pitch in elements); weights (taps, cout_pad, cin) bf16.
+    F-Net extras (include/magnet_hip.h): dil (3x3 dilation), out_ld (write a channel slice: out tensors may then be
+    views), add = (hi, lo, ld) split-bf16 residual input, border = (hp, pad) zero the border outputs, repad (re-address
+    interior rows to a grid with border repad-1), out_bf16 = single bf16 output plane."""
     lib = _conv_protos(load())
     a = MagnetConvArgs()
     for t, n in ((in_hi, "in_hi"), (in_lo, "in_lo"), (w_hi, "w_hi"), (w_lo, "w_lo")):
@@ -346,11 +358,19 @@ def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, 
     a.relu, a.in_ld = int(bool(relu)), int(in_ld)
     if addend is not None:
         a.addend, a.addend_ld = _dev(addend, "addend", torch.float32).data_ptr(), int(addend.shape[1])
+    a.dil, a.out_ld, a.repad = int(dil), int(out_ld), int(repad)
+    if add is not None:
+        a.add_hi, a.add_lo, a.add_ld = _bf16_ptr(add[0], "add_hi"), _bf16_ptr(add[1], "add_lo"), int(add[2])
+    if border is not None:
+        a.border_hp, a.border_pad = int(border[0]), int(border[1])
     if out_f32 is not None:
-        a.out_mode, a.out_f32 = 1, _dev(out_f32, "out_f32", torch.float32).data_ptr()
+        if not out_f32.is_cuda or out_f32.dtype != torch.float32:
+            raise MagnetError("conv_mfma: out_f32 must be a float32 GPU tensor")
+        a.out_mode, a.out_f32 = 1, out_f32.data_ptr()
+    elif out_bf16 is not None:
+        a.out_mode, a.out_hi = 2, _bf16_ptr(out_bf16, "out_bf16")
     else:
-        a.out_mode, a.out_hi, a.out_lo = 0, _dev(out_hi, "out_hi", torch.bfloat16).data_ptr(), \
-            _dev(out_lo, "out_lo", torch.bfloat16).data_ptr()
+        a.out_mode, a.out_hi, a.out_lo = 0, _bf16_ptr(out_hi, "out_hi"), _bf16_ptr(out_lo, "out_lo")
     with torch.cuda.device(in_hi.device):
         _check(lib.magnet_conv_mfma(ctypes.byref(a), _stream(in_hi)), "magnet_conv_mfma")
 
@@ -417,3 +437,58 @@ def conv1x1_chain(in_hi, in_lo, w_hi, w_lo, bias, out, rows, cout_pad):
 
 
 API_SYMBOLS = API_SYMBOLS + ("magnet_depth_metrics",)
+
+
+# ---- F-Net non-GEMM layers (row N3) -------------------------------------------------------------------------------
+API_SYMBOLS = API_SYMBOLS + ("magnet_fnet_stem", "magnet_space_to_depth", "magnet_avgpool_cl", "magnet_upsample_bilinear_cl")
+
+
+def _fnet_protos(lib):
+    if getattr(lib, "_fnet_protos_done", False):
+        return lib
+    I, P = ctypes.c_int32, ctypes.c_void_p
+    lib.magnet_fnet_stem.restype = ctypes.c_int
+    lib.magnet_fnet_stem.argtypes = [P, P, P, P, P, I, I, I, P]
+    lib.magnet_space_to_depth.restype = ctypes.c_int
+    lib.magnet_space_to_depth.argtypes = [P, P, P, P, I, I, I, I, I, P]
+    lib.magnet_avgpool_cl.restype = ctypes.c_int
+    lib.magnet_avgpool_cl.argtypes = [P, P, I, I, I, I, I, I, I, P, P, P]
+    lib.magnet_upsample_bilinear_cl.restype = ctypes.c_int
+    lib.magnet_upsample_bilinear_cl.argtypes = [P, I, I, I, I, P, P, I, I, I, I, I, P]
+    lib._fnet_protos_done = True
+    return lib
+
+
+def fnet_stem(img, wgt, bias, out_hi, out_lo):
+    """(N,3,H,W) fp32 image -> 32-channel split planes (N,H2+2,W2+2,32): 3x3/s2 conv + folded BN + ReLU (F_psmnet.py:40)."""
+    lib = _fnet_protos(load())
+    x = _dev(img, "img", torch.float32)
+    N, C, H, W = x.shape
+    if C != 3:
+        raise MagnetError(f"fnet_stem: expected 3 input channels, got {C}")
+    with torch.cuda.device(x.device):
+        _check(lib.magnet_fnet_stem(x.data_ptr(), _dev(wgt, "wgt", torch.float32).data_ptr(),
+                                    _dev(bias, "bias", torch.float32).data_ptr(), _bf16_ptr(out_hi, "out_hi"),
+                                    _bf16_ptr(out_lo, "out_lo"), N, H, W, _stream(x)), "magnet_fnet_stem")
+
+
+def space_to_depth(in_hi, in_lo, out_hi, out_lo, N, C, H2, W2, opad):
+    lib = _fnet_protos(load())
+    with torch.cuda.device(in_hi.device):
+        _check(lib.magnet_space_to_depth(_bf16_ptr(in_hi, "in_hi"), _bf16_ptr(in_lo, "in_lo"), _bf16_ptr(out_hi, "out_hi"),
+                                         _bf16_ptr(out_lo, "out_lo"), N, C, H2, W2, opad, _stream(in_hi)), "magnet_space_to_depth")
+
+
+def avgpool_cl(in_hi, in_lo, ld, N, h, w, pad, k, C, out_hi, out_lo):
+    lib = _fnet_protos(load())
+    with torch.cuda.device(in_hi.device):
+        _check(lib.magnet_avgpool_cl(_bf16_ptr(in_hi, "in_hi"), _bf16_ptr(in_lo, "in_lo"), ld, N, h, w, pad, k, C,
+                                     _bf16_ptr(out_hi, "out_hi"), _bf16_ptr(out_lo, "out_lo"), _stream(in_hi)), "magnet_avgpool_cl")
+
+
+def upsample_bilinear_cl(x, in_ld, ph, pw, C, out_hi, out_lo, out_ld, N, h, w, pad):
+    lib = _fnet_protos(load())
+    with torch.cuda.device(x.device):
+        _check(lib.magnet_upsample_bilinear_cl(_dev(x, "x", torch.float32).data_ptr(), in_ld, ph, pw, C, _bf16_ptr(out_hi, "out_hi"),
+                                               _bf16_ptr(out_lo, "out_lo"), out_ld, N, h, w, pad, _stream(x)),
+               "magnet_upsample_bilinear_cl")

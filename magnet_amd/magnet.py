@@ -129,6 +129,8 @@ class MAGNET(nn.Module):
         self._work = {}                # cached device workspaces of the MFMA conv path, keyed by shape
         self.hoist_invariant = True    # I >= 2: compute the x_d3 part of G-Net's first layer once per forward
         self._stacks = None
+        self.fnet_mfma = True          # run a PSMNet-structured f_net on the matrix-core path (magnet_amd/fnet.py)
+        self._fnet = None
 
         dnet_fdim = 256
         self.g_net = GNET(ch_in=dnet_fdim + self.n_samples, ch_out=2)
@@ -145,11 +147,12 @@ class MAGNET(nn.Module):
 
     # -- the hot path proper: everything after the backbones --------------------------------------
     def match_and_refine(self, ref_gmms, x_d3, ref_feat_4, nghbr_feat_4, nghbr_gmms, nghbr_poses,
-                         is_valid, cam_intrins, mode="test"):
-        """MAGNET.py:146-175 from backbone outputs.  Returns the list of upsampled (B,2,H,W)."""
+                         is_valid, cam_intrins, mode="test", packed_feats=None):
+        """MAGNET.py:146-175 from backbone outputs.  Returns the list of upsampled (B,2,H,W).
+        packed_feats: (ref_cl, src_pad) straight from the matrix-core F-Net instead of NCHW feature tensors."""
         thres = int(self.weighting.split("CW")[1])
         matcher = CostVolumeCW(ref_feat_4, nghbr_feat_4, nghbr_gmms, nghbr_poses, is_valid, cam_intrins,
-                               thres, feat_dtype=self.feat_dtype, path=self.matcher_path)
+                               thres, feat_dtype=self.feat_dtype, path=self.matcher_path, packed=packed_feats)
         B, _, h, w = ref_gmms.shape
         n_iter = self.train_iter if mode == "train" else self.test_iter
         training = torch.is_grad_enabled() and any(p.requires_grad for p in
@@ -223,11 +226,28 @@ class MAGNET(nn.Module):
             ref_gmms = mono_gmms[:B, ...]
             x_d3 = x_d3[:B, ...]
             nghbr_gmms = mono_gmms[B:, ...]
+            runner = self._fnet_runner()
+            if runner is not None and ref_img.is_cuda:
+                # F-Net on the matrix cores; its last layer writes the matcher's layouts (no NCHW features, no pack)
+                packed = runner.run(torch.cat((ref_img, nghbr_imgs), dim=0), n_ref=B, feat_dtype=self.feat_dtype)
+                return self.match_and_refine(ref_gmms, x_d3, None, None, nghbr_gmms, nghbr_poses, is_valid, cam_intrins,
+                                             mode, packed_feats=packed)
             feat_4 = self.f_net(torch.cat((ref_img, nghbr_imgs), dim=0))                 # MAGNET.py:142
             ref_feat_4 = feat_4[:B, ...]
             nghbr_feat_4 = feat_4[B:, ...]
         return self.match_and_refine(ref_gmms, x_d3, ref_feat_4, nghbr_feat_4, nghbr_gmms, nghbr_poses,
                                      is_valid, cam_intrins, mode)
+
+    def _fnet_runner(self):
+        """FNetMFMA for a PSMNet-structured F-Net (ours or the reference's own class) when conv_backend == 'mfma'."""
+        if self.conv_backend != "mfma" or not self.fnet_mfma:
+            return None
+        if self._fnet is None:
+            from .fnet import FNetMFMA
+            psm = getattr(self.f_net, "f_net", self.f_net)
+            ok = all(hasattr(psm, a) for a in ("firstconv", "layer1", "layer2", "layer3", "layer4", "branch1", "lastconv"))
+            self._fnet = FNetMFMA(psm) if ok else False
+        return self._fnet or None
 
 
 class MAGNET_F(nn.Module):

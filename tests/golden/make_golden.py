@@ -29,7 +29,7 @@ import utils.utils as ref_u                            # noqa: E402  (reference)
 
 from magnet_amd import synth                           # noqa: E402
 from oracle import oracle                              # noqa: E402
-from tests.stubs import StubDNet, StubFNet, make_args, seeded_magnet_weights  # noqa: E402
+from tests.stubs import StubDNet, StubFNet, make_args, seeded_magnet_weights, seeded_fnet_state, procedural_images  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -274,6 +274,21 @@ def main():
           f"(max|d|={np.abs(o_raw - raw9.detach().numpy()).max():.2e}); softmax max|d|="
           f"{np.abs(oracle.softmax_dim1(o_raw) - soft9.numpy()).max():.2e}; grad_ref max|d|={np.abs(o_gr - rf.grad.numpy()).max():.2e} "
           f"grad_src max|d|={np.abs(o_gs - sf.grad.numpy()).max():.2e} (|grad| max {rf.grad.abs().max():.2f}/{sf.grad.abs().max():.2f})")
+
+    # ---- G10 F-Net (PSMNet, eval mode) on a procedural image with crc-seeded weights: sparse output samples ----------
+    from models.submodules.F_psmnet import PSMNet as RefPSMNet
+    ref_f = seeded_fnet_state(RefPSMNet(feature_dim=64), seed=10).eval()
+    img10 = procedural_images(2, 256, 320)
+    with torch.no_grad():
+        f10 = ref_f(img10)                                                       # (2, 64, 64, 80)
+    out["G10_feat_sparse"] = f10[:, :, ::4, ::4].contiguous().numpy()
+    out["G10_feat_absmean"] = f10.abs().mean(dim=(0, 2, 3)).numpy()
+    from magnet_amd.fnet import PSMNet as OurPSMNet
+    ours = seeded_fnet_state(OurPSMNet(feature_dim=64), seed=10).eval()
+    with torch.no_grad():
+        o10 = ours(img10)
+    print(f"[G10] F-Net reference output {tuple(f10.shape)} |max| {f10.abs().max():.3f}; magnet_amd.fnet.PSMNet (torch path) "
+          f"max|d| = {(o10 - f10).abs().max():.2e}")
 
     path = os.path.join(HERE, "golden_v1.npz")
     np.savez_compressed(path, **out)

@@ -61,3 +61,42 @@ def seeded_magnet_weights(model, seed=0):
             for name, p in sorted(mod.state_dict().items()):
                 scale = 0.05 if p.dim() > 1 else 0.01
                 p.copy_(torch.randn(p.shape, generator=g) * scale)
+
+
+def seeded_fnet_state(module, seed=0):
+    """Deterministic, platform-independent parameters/buffers for a PSMNet-structured module (ours or the reference's):
+    every tensor is drawn from numpy's MT19937 seeded by crc32(key) + seed, so the golden generator (reference class)
+    and the tests (magnet_amd.fnet.PSMNet) rebuild identical weights without a 13 MB fixture."""
+    import zlib
+    import numpy as np
+    sd = module.state_dict()
+    out = {}
+    for key, t in sd.items():
+        rs = np.random.RandomState((zlib.crc32(key.encode()) + seed) & 0x7fffffff)
+        if key.endswith("num_batches_tracked"):
+            out[key] = torch.tensor(100, dtype=t.dtype)
+        elif t.dim() == 4:                                      # conv weight: N(0, sqrt(2/(k*k*cout))) like the reference's init
+            cout, _, kh, kw = t.shape
+            out[key] = torch.from_numpy(rs.standard_normal(tuple(t.shape)) * np.sqrt(2.0 / (kh * kw * cout))).float()
+        elif key.endswith("running_var"):
+            out[key] = torch.from_numpy(rs.uniform(0.5, 1.5, tuple(t.shape))).float()
+        elif key.endswith("running_mean"):
+            out[key] = torch.from_numpy(rs.standard_normal(tuple(t.shape)) * 0.1).float()
+        elif key.endswith("weight"):                            # BN gamma; small on the residual branch (25 un-normalised sums)
+            lo, hi = (0.1, 0.3) if ".conv2.1." in key else (0.5, 1.0)
+            out[key] = torch.from_numpy(rs.uniform(lo, hi, tuple(t.shape))).float()
+        else:                                                   # BN beta
+            out[key] = torch.from_numpy(rs.standard_normal(tuple(t.shape)) * 0.1).float()
+    module.load_state_dict(out)
+    return module
+
+
+def procedural_images(N, H, W):
+    """Deterministic (N,3,H,W) fp32 test images from closed-form fp64 expressions (no RNG dependence)."""
+    import numpy as np
+    y, x = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    img = np.empty((N, 3, H, W), np.float64)
+    for n in range(N):
+        for c in range(3):
+            img[n, c] = np.sin(0.05 * x * (c + 1) + 0.3 * n) * np.cos(0.07 * y + 0.5 * c) + 0.1 * ((x * y + 3 * n) % 7) - 0.3
+    return torch.from_numpy(img.astype(np.float32))
