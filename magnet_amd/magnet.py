@@ -129,6 +129,10 @@ class MAGNET(nn.Module):
         self._work = {}                # cached device workspaces of the MFMA conv path, keyed by shape
         self.hoist_invariant = True    # I >= 2: compute the x_d3 part of G-Net's first layer once per forward
         self._stacks = None
+        # mask head on a side stream next to matcher + G-Net.  Measured on MI355X: no gain (10.15 vs 10.05 ms per C2 step) —
+        # the workgroups of the two queues do not co-reside usefully; kept as an option, off by default.
+        self.overlap_mask_head = False
+        self._side = {}
         self.fnet_mfma = True          # run a PSMNet-structured f_net on the matrix-core path (magnet_amd/fnet.py)
         self._fnet = None
 
@@ -200,13 +204,28 @@ class MAGNET(nn.Module):
                         torch.zeros((rows, ctot), dtype=torch.bfloat16, device=dev)),     # channels stay zero
                 "cost": torch.empty((B, D, h, w), dtype=torch.float32, device=dev)}
         gin_hi, gin_lo = work["gin"]
-        lib.pack_split(x_d3.detach().float().contiguous(), gin_hi, gin_lo, ctot, Dp)
-        mask_pad, mask_ld = m_stack.run(gin_hi[:, Dp:], gin_lo[:, Dp:], ctot, rows, wp, work)       # MAGNET.py:172
+        x_d3 = x_d3.detach().float().contiguous()
+        # The mask head depends on x_d3 only.  It is MFMA-bound while the matcher is VALU/latency-bound and the packs are
+        # HBM-bound, so it runs on a side stream next to [matcher -> G-Net]: pack(x_d3) -> mask head || matcher, with
+        # events where the chains meet (G-Net reads the packed x_d3; the upsampling reads the mask).
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if self.overlap_mask_head else main
+        if side is not main:
+            side.wait_stream(main)                   # x_d3 is ready; the previous forward no longer reads `gin`
+            x_d3.record_stream(side)
+        with torch.cuda.stream(side):
+            lib.pack_split(x_d3, gin_hi, gin_lo, ctot, Dp)
+            ev_pack = torch.cuda.Event(); ev_pack.record(side)
+            mask_pad, mask_ld = m_stack.run(gin_hi[:, Dp:], gin_lo[:, Dp:], ctot, rows, wp, work.setdefault("mask", {}))  # MAGNET.py:172
+            ev_mask = torch.cuda.Event(); ev_mask.record(side)
         pred_list = [ref_gmms.detach().float().contiguous()]
         # With more than one refinement iteration the x_d3 part of G-Net's first layer (256 of the 256+D input
         # channels) is loop-invariant: compute W_x * x_d3 once, add it in the epilogue of the per-iteration
         # convolution over the D cost channels only (K = 9*(256+D) -> 9*round_up(D,32) per iteration).
-        partial = g_stack.run_invariant(gin_hi, gin_lo, ctot, rows, wp, work, Dp) if (n_iter >= 2 and self.hoist_invariant) else None
+        partial = None
+        if n_iter >= 2 and self.hoist_invariant:
+            main.wait_event(ev_pack)
+            partial = g_stack.run_invariant(gin_hi, gin_lo, ctot, rows, wp, work, Dp)
         for _ in range(n_iter):
             if self.matcher_path in (0, 2):
                 # the candidate-lane kernel writes the D cost channels of the G-Net input buffer directly
@@ -214,8 +233,10 @@ class MAGNET(nn.Module):
             else:
                 matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out=work["cost"])
                 lib.pack_split(work["cost"], gin_hi, gin_lo, ctot, 0)
+            main.wait_event(ev_pack)                                                                 # x_d3 channels are in place
             g_out, g_ld = g_stack.run(gin_hi, gin_lo, ctot, rows, wp, work, first_addend=partial, n_var=Dp)  # MAGNET.py:62
             pred_list.append(lib.gaussian_update_cl(g_out, g_ld, pred_list[-1], h, w))               # MAGNET.py:60-69
+        main.wait_event(ev_mask)
         return [lib.upsample_depth_cl(pred, mask_pad, mask_ld) for pred in pred_list[1:]]            # MAGNET.py:173
 
     def forward(self, ref_img, nghbr_imgs, nghbr_poses, is_valid, cam_intrins, mode="train"):
@@ -237,6 +258,12 @@ class MAGNET(nn.Module):
             nghbr_feat_4 = feat_4[B:, ...]
         return self.match_and_refine(ref_gmms, x_d3, ref_feat_4, nghbr_feat_4, nghbr_gmms, nghbr_poses,
                                      is_valid, cam_intrins, mode)
+
+    def _side_stream(self, dev):
+        st = self._side.get(str(dev))
+        if st is None:
+            st = self._side[str(dev)] = torch.cuda.Stream(device=dev)
+        return st
 
     def _fnet_runner(self):
         """FNetMFMA for a PSMNet-structured F-Net (ours or the reference's own class) when conv_backend == 'mfma'."""
