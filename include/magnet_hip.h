@@ -175,6 +175,14 @@ typedef struct MagnetConvArgs {
     int32_t      repad;                    /* > 0 (needs border_hp): only interior positions are written, re-addressed into
                                               grids with a (repad-1)-wide border: hands the last layer's output to the
                                               matcher's layouts (border 0 = reference features, 1 = source features) */
+    const void  *tail_w_hi, *tail_w_lo;    /* optional fused 1x1 tail (models/MAGNET.py:53-55, :113-115): after THIS layer (cout_pad
+                                              must be 128; bias / relu / addend apply) the workgroup's 128-row tile stays in LDS and
+                                              relu(1x1 128->128), relu(1x1 128->128), 1x1 128->tail_cout_pad run in the same kernel.
+                                              Weights / bias laid out as for magnet_conv1x1_chain.  The only output is fp32
+                                              (rows, tail_cout_pad) at out_f32 (out_mode, out_hi/lo, out_ld are ignored): the three
+                                              hidden (rows,128) tensors never reach HBM. */
+    const float *tail_bias;
+    int32_t      tail_cout_pad;            /* 16, 128 or 144 */
 } MagnetConvArgs;                          /* out_mode 2: one bf16 plane (round-to-nearest-even) at out_hi */
 
 MAGNET_API int magnet_conv_mfma(const MagnetConvArgs *args, void *stream);

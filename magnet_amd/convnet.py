@@ -60,6 +60,9 @@ class ConvStackMFMA:
         # workgroup per CU, so its load phase is not overlapped, whereas the separate launches are HBM-bound at
         # high occupancy.  Off by default; kept (and tested) as the starting point for a 64-row-tile variant.
         self.fuse_tail = False
+        # The same three 1x1 layers fused into the EPILOGUE of the stack's first (3x3) layer: the 128 x 128 tile is already
+        # on the CU, weights come straight from L2, LDS need stays at the K ring's 64 KB (2 workgroups per CU).
+        self.fuse_epilogue = True
         self._chain = None
         self._packed = None
         self._key = None
@@ -152,6 +155,21 @@ class ConvStackMFMA:
             # first layer over the per-iteration channels only; the invariant part arrives as `first_addend`
             packs = [self.packed_first_split(in_hi.device, n_var)[0]] + list(packs[1:])
         cur_hi, cur_lo, cur_ld = in_hi, in_lo, in_ld
+        if self._chain is not None and self.fuse_epilogue:
+            pk, ch = packs[0], self._chain
+            key = ("out", rows, ch["cout_pad"])
+            if key not in work:
+                work[key] = torch.empty((rows, ch["cout_pad"]), dtype=torch.float32, device=in_hi.device)
+            sink = ConvStackMFMA.event_sink
+            if sink is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                sink.append((e0, e1, 2.0 * rows * (pk["cout_pad"] * pk["cin"] * pk["taps"] + 128 * (256 + ch["cout_pad"])), pk["taps"]))
+            lib.conv_mfma(cur_hi, cur_lo, cur_ld, pk["cin"], pk["w_hi"], pk["w_lo"], pk["bias"], pk["taps"], wp, pk["relu"], rows,
+                          out_f32=work[key], addend=first_addend, tail=(ch["w_hi"], ch["w_lo"], ch["bias"], ch["cout_pad"]))
+            if sink is not None:
+                e1.record()
+            return work[key], ch["cout_pad"]
         if self._chain is not None and self.fuse_tail and first_addend is None:
             pk = packs[0]
             key = ("hid", 0, rows, 128)

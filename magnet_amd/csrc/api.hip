@@ -192,7 +192,16 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     if (!a) return fail(MAGNET_E_NULL, "magnet_conv_mfma: args is NULL");
     if (!a->in_hi || !a->in_lo || !a->w_hi || !a->w_lo || !a->bias) return fail(MAGNET_E_NULL, "magnet_conv_mfma: NULL input pointer");
     if (a->out_mode < 0 || a->out_mode > 2) return fail(MAGNET_E_DIM, "magnet_conv_mfma: out_mode must be 0, 1 or 2");
-    if (a->out_mode == 0 ? (!a->out_hi || !a->out_lo) : (a->out_mode == 1 ? !a->out_f32 : !a->out_hi))
+    const bool tail = a->tail_w_hi != nullptr;
+    if (tail) {
+        if (!a->tail_w_lo || !a->tail_bias || !a->out_f32) return fail(MAGNET_E_NULL, "magnet_conv_mfma: fused tail needs tail_w_lo, tail_bias and out_f32");
+        if (a->cout_pad != 128 || (a->tail_cout_pad != 16 && a->tail_cout_pad != 128 && a->tail_cout_pad != 144))
+            return fail(MAGNET_E_DIM, "magnet_conv_mfma: fused tail needs cout_pad == 128 and tail_cout_pad in {16,128,144}");
+        if (!aligned16(a->tail_w_hi) || !aligned16(a->tail_w_lo) || !aligned16(a->tail_bias) || !aligned16(a->out_f32))
+            return fail(MAGNET_E_ALIGN, "magnet_conv_mfma: fused tail pointers must be 16-byte aligned");
+        if (a->border_hp || a->repad || a->add_hi) return fail(MAGNET_E_DIM, "magnet_conv_mfma: fused tail excludes border / repad / residual input");
+    }
+    if (!tail && (a->out_mode == 0 ? (!a->out_hi || !a->out_lo) : (a->out_mode == 1 ? !a->out_f32 : !a->out_hi)))
         return fail(MAGNET_E_NULL, "magnet_conv_mfma: NULL output pointer");
     if (a->rows <= 0 || a->cin <= 0 || (a->cin % 32) != 0) return fail(MAGNET_E_DIM, "magnet_conv_mfma: rows > 0 and cin %% 32 == 0 required (cin=%d)", a->cin);
     if (a->taps != 1 && a->taps != 4 && a->taps != 9) return fail(MAGNET_E_DIM, "magnet_conv_mfma: taps must be 1, 4 or 9");
@@ -200,7 +209,7 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     if (!((a->cout_pad > 0 && a->cout_pad % 128 == 0) || a->cout_pad == 144 || a->cout_pad == 16 || a->cout_pad == 32 || a->cout_pad == 64))
         return fail(MAGNET_E_DIM, "magnet_conv_mfma: cout_pad=%d unsupported (multiple of 128, or 144, 64, 32, 16)", a->cout_pad);
     if (!aligned16(a->in_hi) || !aligned16(a->in_lo) || !aligned16(a->w_hi) || !aligned16(a->w_lo) ||
-        (a->out_mode == 0 ? (!aligned16(a->out_hi) || !aligned16(a->out_lo)) : (a->out_mode == 1 ? !aligned16(a->out_f32) : !aligned16(a->out_hi))))
+        (!tail && (a->out_mode == 0 ? (!aligned16(a->out_hi) || !aligned16(a->out_lo)) : (a->out_mode == 1 ? !aligned16(a->out_f32) : !aligned16(a->out_hi)))))
         return fail(MAGNET_E_ALIGN, "magnet_conv_mfma: pointers must be 16-byte aligned");
     if (a->dil < 0 || a->dil > 8) return fail(MAGNET_E_DIM, "magnet_conv_mfma: dil=%d out of range", a->dil);
     magnet::ConvParams p;
@@ -232,6 +241,8 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     }
     if (a->repad < 0 || (a->repad && !a->border_hp)) return fail(MAGNET_E_DIM, "magnet_conv_mfma: repad needs border_hp");
     p.repad = a->repad;
+    p.tail_w_hi = (const uint16_t*)a->tail_w_hi; p.tail_w_lo = (const uint16_t*)a->tail_w_lo; p.tail_bias = a->tail_bias;
+    p.tail_cout = a->tail_cout_pad;
     hipError_t e = magnet::launch_conv_mfma(p, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_conv_mfma launch");
 }

@@ -23,6 +23,10 @@ struct ConvParams {
     int img_rows, hp, pad;                            // img_rows = hp*wp > 0: rows are decoded to (image, y, x) and outputs of
                                                       // the `pad`-wide border are written as zeros (next layer's zero padding)
     int repad;                                        // > 0: interior rows only, re-addressed to a grid with border repad-1
+    // fused 1x1 tail (cout_pad == 128 only): relu(1x1 128->128), relu(1x1 128->128), 1x1 128->tail_cout applied to the
+    // workgroup's tile before it leaves the CU; weights [128][128],[128][128],[tail_cout][128] concatenated, bias likewise
+    const uint16_t* tail_w_hi; const uint16_t* tail_w_lo; const float* tail_bias;
+    int tail_cout;                                    // 16, 128 or 144; result fp32 (rows, tail_cout) at out_f32
 };
 
 struct ChainParams {

@@ -54,7 +54,72 @@ __device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) 
 // NF = 16-column fragments of the workgroup tile (BN = NF*16: 128, 144 or 16 channels);
 // WN = waves along N (2: 2x2 waves; 1: 4x1 waves); CV_BM = rows of the workgroup tile (128 or 256)
 // SPB = K stages per barrier interval (the LDS ring holds 2*SPB stages)
-template <int NF, int WN, int CV_BM, int SPB>
+__device__ __forceinline__ int act_swz(int row, int slot) { return row * 256 + ((slot ^ (row & 15)) << 4); }
+
+// One 1x1 layer of the fused tail: this wave's 32 tile rows x (NF*16) output channels over K = 128, activations read
+// from the LDS tile (act_swz layout), weight fragments straight from global memory (64 KB per layer, L2-resident; no LDS
+// staging, so no barrier: the rows are wave-private).  Operands are swapped (weights = MFMA A operand): the accumulator is
+// C^T — a lane holds 4 CONSECUTIVE output channels of one row.
+template <int NF, bool LAST>
+__device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, const uint16_t* __restrict__ w_lo,
+                                           const float* __restrict__ bias, unsigned char* act_hi, unsigned char* act_lo,
+                                           float* __restrict__ out, int out_ld, long long row0, long long rows, int lane, int wv) {
+    f32x4_t acc[NF][2];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) { acc[n][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[n][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    const int frow = lane & 15, kslot = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        bf16x8_t xh[2], xl[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int row = wv * 32 + m * 16 + frow;
+            xh[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_hi + act_swz(row, kk * 4 + kslot)));
+            xl[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_lo + act_swz(row, kk * 4 + kslot)));
+        }
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const size_t e = (size_t)(n * 16 + frow) * 128 + kk * 32 + kslot * 8;
+            const bf16x8_t wh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_hi + e));
+            const bf16x8_t wl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_lo + e));
+            acc[n][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[0], acc[n][0], 0, 0, 0);
+            acc[n][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[1], acc[n][1], 0, 0, 0);
+            acc[n][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[0], acc[n][0], 0, 0, 0);
+            acc[n][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[1], acc[n][1], 0, 0, 0);
+            acc[n][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[0], acc[n][0], 0, 0, 0);
+            acc[n][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[1], acc[n][1], 0, 0, 0);
+        }
+    }
+    // all of this wave's reads of its rows are done (same wave, in-order LDS); publish the layer's output in place
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int ch = n * 16 + (lane >> 4) * 4;
+            const int trow = wv * 32 + m * 16 + (lane & 15);
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + ch);
+            float v[4] = {acc[n][m][0] + b4.x, acc[n][m][1] + b4.y, acc[n][m][2] + b4.z, acc[n][m][3] + b4.w};
+            if constexpr (!LAST) {
+                uint16_t h[4], l[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = v[r] < 0.f ? 0.f : v[r]; split_bf16(v[r], h[r], l[r]); }
+                const int off = act_swz(trow, ch >> 3) + (ch & 7) * 2;          // 8 bytes: channels ch..ch+3
+                *reinterpret_cast<uint2*>(act_hi + off) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                *reinterpret_cast<uint2*>(act_lo + off) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+            } else {
+                const long long row = row0 + trow;
+                if (row < rows) *reinterpret_cast<float4*>(out + (size_t)row * out_ld + ch) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// TAIL = 0: plain layer.  TAIL = 16-column fragments of the fused tail's last layer (1, 8 or 9): see ConvParams::tail_*.
+template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int BN = NF * 16;
     constexpr int A_PT = CV_BM / 64;                           // 16-byte vectors per thread per A plane (2 or 4)
@@ -181,6 +246,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         __syncthreads();                                      // next half landed; everyone done with this half
     }
 
+    if constexpr (TAIL > 0) {
+        // ---- fused 1x1 tail: the 128 x 128 tile (bias, ReLU, re-split) becomes the LDS-resident input of three 1x1 layers ----
+        static_assert(NF == 8 && WN == 2 && CV_BM == 128, "the fused tail is written for the 128 x 128 tile");
+        unsigned char* act_hi = smem;                                   // [128 rows][256 B]; the K ring is dead (barrier above)
+        unsigned char* act_lo = smem + 128 * 256;
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+            for (int n = 0; n < NFW; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int trow = wm * (MF * 16) + m * 16 + (lane >> 4) * 4 + r;
+                    const int ch = wn * (NFW * 16) + n * 16 + (lane & 15);
+                    float x = acc[m][n][r];
+                    if (p.addend) {
+                        const long long row = row0 + trow;
+                        x += p.addend[(size_t)(row < p.rows ? row : p.rows - 1) * p.addend_ld + ch];
+                    }
+                    x += p.bias[ch];
+                    x = (p.relu && x < 0.f) ? 0.f : x;
+                    uint16_t h, l;
+                    split_bf16(x, h, l);
+                    const int off = act_swz(trow, ch >> 3) + (ch & 7) * 2;
+                    *reinterpret_cast<uint16_t*>(act_hi + off) = h;
+                    *reinterpret_cast<uint16_t*>(act_lo + off) = l;
+                }
+        __syncthreads();
+        tail_layer<8, false>(p.tail_w_hi, p.tail_w_lo, p.tail_bias, act_hi, act_lo, nullptr, 0, row0, p.rows, lane, wv);
+        tail_layer<8, false>(p.tail_w_hi + 128 * 128, p.tail_w_lo + 128 * 128, p.tail_bias + 128, act_hi, act_lo, nullptr, 0, row0,
+                             p.rows, lane, wv);
+        tail_layer<TAIL, true>(p.tail_w_hi + 2 * 128 * 128, p.tail_w_lo + 2 * 128 * 128, p.tail_bias + 256, act_hi, act_lo, p.out_f32,
+                               p.tail_cout, row0, p.rows, lane, wv);
+        return;
+    }
+
     // ---- epilogue through LDS, one 16-row fragment per wave at a time: [16 rows][NFW*16] fp32 per wave ----
     constexpr int WCOLS = NFW * 16, SROW = WCOLS + 4;          // +4 floats row pad
     float* stage = reinterpret_cast<float*>(smem) + wv * (16 * SROW);
@@ -267,17 +367,17 @@ static size_t conv_lds_bytes() {
     return tiles > stage ? tiles : stage;
 }
 
-template <int NF, int WN, int BM, int SPB>
+template <int NF, int WN, int BM, int SPB, int TAIL = 0>
 static hipError_t launch_conv_nf(const ConvParams& p, hipStream_t s) {
     const dim3 grid((unsigned)((p.rows + BM - 1) / BM), (unsigned)(p.cout_pad / (NF * 16))), block(256);
     const size_t lds = conv_lds_bytes<NF, WN, BM, SPB>();
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {          // > 64 KiB of dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB, TAIL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM, SPB>), grid, block, lds, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM, SPB, TAIL>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
@@ -286,6 +386,13 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
     // Measured alternatives on the G-Net 3x3 layer (64 frames; this configuration: 2.31 ms): 64-row tile / 3 workgroups
     // per CU 2.80 ms; two K stages per barrier (4-stage ring, 128 KB LDS, 1 workgroup per CU) 3.51 ms; 256-row tile
     // (1 workgroup per CU) 3.45 ms.  The kernel lives on inter-workgroup overlap: keep 2 workgroups per CU.
+    if (p.tail_w_hi) {                           // 3x3 (or 1x1) 128-wide layer + its three 1x1 successors in one kernel
+        if (p.cout_pad != 128) return hipErrorInvalidValue;
+        if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 128, 1, 1>(p, s);
+        if (p.tail_cout == 128) return launch_conv_nf<8, 2, 128, 1, 8>(p, s);
+        if (p.tail_cout == 144) return launch_conv_nf<8, 2, 128, 1, 9>(p, s);
+        return hipErrorInvalidValue;
+    }
     if (p.cout_pad % 128 == 0) return launch_conv_nf<8, 2, 128, 1>(p, s);
     if (p.cout_pad == 144) return launch_conv_nf<9, 1, 128, 1>(p, s);
     if (p.cout_pad == 16)  return launch_conv_nf<1, 1, 128, 1>(p, s);
@@ -308,8 +415,6 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
 //     layers, 16-byte fp32 global stores for the last one;
 //   * activation tile rows are 256 B with slot ^= (row & 15) (conflict-free fragment reads); weight tiles are
 //     streamed per 32-wide K chunk through the same double-buffered swizzled image as conv_mfma_kernel.
-__device__ __forceinline__ int act_swz(int row, int slot) { return row * 256 + ((slot ^ (row & 15)) << 4); }
-
 // one layer: acc[n][m] over K = 128 for this wave's 32 rows; NF = output fragments (channels / 16)
 template <int NF, bool LAST>
 __device__ __forceinline__ void chain_layer(const ChainParams& p, const uint16_t* __restrict__ w_hi,

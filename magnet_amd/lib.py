@@ -311,6 +311,8 @@ class MagnetConvArgs(ctypes.Structure):
         ("dil", ctypes.c_int32), ("out_ld", ctypes.c_int32),
         ("add_hi", ctypes.c_void_p), ("add_lo", ctypes.c_void_p), ("add_ld", ctypes.c_int32),
         ("border_hp", ctypes.c_int32), ("border_pad", ctypes.c_int32), ("repad", ctypes.c_int32),
+        ("tail_w_hi", ctypes.c_void_p), ("tail_w_lo", ctypes.c_void_p), ("tail_bias", ctypes.c_void_p),
+        ("tail_cout_pad", ctypes.c_int32),
     ]
 
 
@@ -341,12 +343,13 @@ def _bf16_ptr(t, name):
 
 
 def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, out_hi=None, out_lo=None, out_f32=None,
-              addend=None, dil=0, out_ld=0, add=None, border=None, repad=0, out_bf16=None):
+              addend=None, dil=0, out_ld=0, add=None, border=None, repad=0, out_bf16=None, tail=None):
     """One convolution layer on the matrix cores.  in_hi/in_lo: bf16 tensors whose data_ptr is row 0 (possibly a
     channel-offset view of a wider buffer, `in_ld` = its row pitch in elements); weights (taps, cout_pad, cin) bf16.
     F-Net extras (include/magnet_hip.h): dil (3x3 dilation), out_ld (write a channel slice: out tensors may then be
     views), add = (hi, lo, ld) split-bf16 residual input, border = (hp, pad) zero the border outputs, repad (re-address
-    interior rows to a grid with border repad-1), out_bf16 = single bf16 output plane."""
+    interior rows to a grid with border repad-1), out_bf16 = single bf16 output plane.
+    tail = (w_hi, w_lo, bias, cout_pad): the stack's three 1x1 successors fused into this launch (result in out_f32)."""
     lib = _conv_protos(load())
     a = MagnetConvArgs()
     for t, n in ((in_hi, "in_hi"), (in_lo, "in_lo"), (w_hi, "w_hi"), (w_lo, "w_lo")):
@@ -363,6 +366,9 @@ def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, 
         a.add_hi, a.add_lo, a.add_ld = _bf16_ptr(add[0], "add_hi"), _bf16_ptr(add[1], "add_lo"), int(add[2])
     if border is not None:
         a.border_hp, a.border_pad = int(border[0]), int(border[1])
+    if tail is not None:
+        a.tail_w_hi, a.tail_w_lo = _bf16_ptr(tail[0], "tail w_hi"), _bf16_ptr(tail[1], "tail w_lo")
+        a.tail_bias, a.tail_cout_pad = _dev(tail[2], "tail bias", torch.float32).data_ptr(), int(tail[3])
     if out_f32 is not None:
         if not out_f32.is_cuda or out_f32.dtype != torch.float32:
             raise MagnetError("conv_mfma: out_f32 must be a float32 GPU tensor")

@@ -16,13 +16,15 @@ def _stack(cin, cout_last, seed):
     return seq.eval()
 
 
-def _run_stack(seq, x, gpu, in_map=None, fuse_tail=True):
+def _run_stack(seq, x, gpu, in_map=None, fuse_tail="epilogue"):
     """x: (B, C, h, w) fp32 CPU -> interior of the stack's fp32 output, (B, cout, h, w)."""
     from magnet_amd import lib
     from magnet_amd.convnet import ConvStackMFMA
     B, C, h, w = x.shape
     st = ConvStackMFMA(seq.to(gpu), in_map=in_map)
-    st.fuse_tail = fuse_tail
+    # "epilogue": 1x1 tail fused into the 3x3 kernel (default); "chain": separate fused-chain kernel; "separate": one launch per layer
+    st.fuse_epilogue = fuse_tail == "epilogue"
+    st.fuse_tail = fuse_tail == "chain"
     ctot = st.cin_pad()
     rows = B * (h + 2) * (w + 2)
     hi = torch.zeros((rows, ctot), dtype=torch.bfloat16, device=gpu); lo = torch.zeros_like(hi)
@@ -38,7 +40,7 @@ def _run_stack(seq, x, gpu, in_map=None, fuse_tail=True):
     return o
 
 
-@pytest.mark.parametrize("fuse_tail", [True, False])
+@pytest.mark.parametrize("fuse_tail", ["epilogue", "chain", "separate"])
 @pytest.mark.parametrize("cin,cout,h,w,B", [(320, 2, 12, 16, 2), (256, 144, 9, 21, 1), (64, 2, 30, 40, 3)])
 def test_conv_stack_matches_fp32(hip_lib, gpu, cin, cout, h, w, B, fuse_tail):
     seq = _stack(cin, cout, seed=cin + cout)
