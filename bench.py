@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 generic gather kernel, 2 window/MFMA kernel")
     ap.add_argument("--conv-backend", default="mfma", choices=["mfma", "torch"],
                     help="g_net/mask_head convolutions: bf16x3 MFMA kernel (default) or nn.Conv2d on MIOpen")
+    ap.add_argument("--no-fuse-tail", action="store_true", help="one launch per 1x1 layer instead of the fused epilogue")
     ap.add_argument("--overlap", action="store_true", help="run the mask head on a side stream (measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-only", action="store_true", help="step = the fused cost-volume kernel alone")
@@ -155,6 +156,7 @@ def main():
         model_cpu = copy.deepcopy(model).eval()
     model = model.to(device).eval()
     model.overlap_mask_head = a.overlap
+    model.fuse_conv_tail = not a.no_fuse_tail
     bcast_bytes = mdist.broadcast_module_(model, src=0)   # the one RCCL collective (weights), xGMI
 
     inp = device_inputs(wl, B, seed=1000 + rank, device=device)

@@ -188,7 +188,13 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                     g0 = *reinterpret_cast<const CGmmPair*>(sgm + qi * 8u);
                     g1 = *reinterpret_cast<const CGmmPair*>(sgm + (qi + (uint32_t)Wp) * 8u);
                 }
-                {
+                // gate = inwin && |z - mu_w| < kappa sigma_w (homography.py:157-158), evaluated from the leaders' tap registers.
+                // Dev option (path bit 16 << 8): SPECULATIVE order — correlate every distinct IN-IMAGE quad and apply the gate
+                // when the result is accumulated, so the feature loads do not wait for the (mu,sigma) taps (one memory round
+                // trip per iteration instead of two).  Same results; measured SLOWER (C2 1.97 vs 1.89 ms, D=5 0.88 vs 0.67,
+                // C4 2.10 vs 1.65): the extra (item, tap) dot products cost more than the round trip saves.
+                bool gate = false;
+                auto eval_gate = [&]() {
                     const unsigned long long lb = __ballot(lead);
                     const unsigned long long le = lb & (~0ull >> (63 - lane));    // leaders at or below this lane
                     const int ldr = 63 - __builtin_clzll(le | 1ull);              // nearest one (lane 0 if none: unused)
@@ -201,19 +207,22 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                     g1.sg0 = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(g1.sg0)));
                     g1.mu1 = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(g1.mu1)));
                     g1.sg1 = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(g1.sg1)));
-                }
-                const float mu_w = bilerp(g0.mu0, g0.mu1, g1.mu0, g1.mu1, t);
-                const float sg_w = bilerp(g0.sg0, g0.sg1, g1.sg0, g1.sg1, t);
-                bool gate = inwin && (__builtin_fabsf(zw - mu_w) < sg_w * p.kappa);   // homography.py:157-158
-                if (p.ablate & 2) gate = inwin && ((j0 & 3) != 0);                // dev: taps skipped, ~75 % open
-                if (p.ablate & 8) gate = false;                                   // dev: geometry only
-                if (p.mode_f) gate = inwin;                                       // est_costvolume_F has no gate
+                    const float mu_w = bilerp(g0.mu0, g0.mu1, g1.mu0, g1.mu1, t);
+                    const float sg_w = bilerp(g0.sg0, g0.sg1, g1.sg0, g1.sg1, t);
+                    gate = inwin && (__builtin_fabsf(zw - mu_w) < sg_w * p.kappa);    // homography.py:157-158
+                    if (p.ablate & 2) gate = inwin && ((j0 & 3) != 0);                // dev: taps skipped, ~75 % open
+                    if (p.ablate & 8) gate = false;                                   // dev: geometry only
+                    if (p.mode_f) gate = inwin;                                       // est_costvolume_F has no gate
+                };
+                const bool spec = (p.ablate & 16) && !(p.ablate & 8);
+                if (!spec) eval_gate();
+                const bool open = spec ? inwin : gate;                               // lanes whose quad becomes an item
 
                 // ---------------- distinct open quads of the wave -> items ----------------
-                const uint32_t key = gate ? qi : KEY_CLOSED;
+                const uint32_t key = open ? qi : KEY_CLOSED;
                 uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)KEY_CLOSED, (int)key, 0x138, 0xf, 0xf, false);  // wave_shr:1
                 if (j0 == 0) prev = KEY_CLOSED;                                   // first candidate of a pixel group
-                const bool fresh = gate && (key != prev);
+                const bool fresh = open && (key != prev);
                 const unsigned long long bal = __ballot(fresh);
                 const int nitems = __popcll(bal);
                 if (nitems == 0) continue;                                        // wave-uniform: nothing open in this view
@@ -256,7 +265,8 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 }
                 wave_lds_fence();
 
-                // ---------------- bilinear combine + fp64 view accumulation ----------------
+                // ---------------- gate (speculative order), bilinear combine + fp64 view accumulation ----------------
+                if (spec) eval_gate();
                 if (gate) {
                     const float4 c4 = *reinterpret_cast<const float4*>(ctab + myitem * 4);
                     const float c = bilerp(c4.x, c4.y, c4.z, c4.w, t);

@@ -133,6 +133,7 @@ class MAGNET(nn.Module):
         # the workgroups of the two queues do not co-reside usefully; kept as an option, off by default.
         self.overlap_mask_head = False
         self._side = {}
+        self.fuse_conv_tail = True     # 1x1 layers of g_net / mask_head fused into their 3x3 layer's epilogue
         self.fnet_mfma = True          # run a PSMNet-structured f_net on the matrix-core path (magnet_amd/fnet.py)
         self._fnet = None
 
@@ -193,6 +194,7 @@ class MAGNET(nn.Module):
             self._stacks = (ConvStackMFMA(self.g_net.gnet, in_map=[(0, D, 0), (D, 256, Dp)]),
                             ConvStackMFMA(self.mask_head))
         g_stack, m_stack = self._stacks
+        g_stack.fuse_epilogue = m_stack.fuse_epilogue = self.fuse_conv_tail
         ctot = g_stack.cin_pad()
         rows, wp = B * (h + 2) * (w + 2), w + 2
         wkey = (str(dev), B, h, w, ctot)
