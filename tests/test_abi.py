@@ -32,12 +32,14 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert hip_lib.magnet_version() == 100
 
 
-def test_struct_layout_matches_c(hip_lib):
-    from magnet_amd.lib import MagnetCostVolumeArgs as A
+@pytest.mark.parametrize("struct", ["MagnetCostVolumeArgs", "MagnetConvArgs"])
+def test_struct_layout_matches_c(hip_lib, struct):
+    from magnet_amd import lib as L
+    A = getattr(L, struct)
     fields = [f[0] for f in A._fields_]
-    prog = '#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%%zu", sizeof(MagnetCostVolumeArgs));' % HEADER
+    prog = '#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%%zu", sizeof(%s));' % (HEADER, struct)
     for f in fields:
-        prog += 'printf(" %%zu", offsetof(MagnetCostVolumeArgs, %s));' % f
+        prog += 'printf(" %%zu", offsetof(%s, %s));' % (struct, f)
     prog += "return 0;}\n"
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c"); exe = os.path.join(d, "t")
@@ -62,6 +64,30 @@ def test_argument_errors_are_codes_not_crashes(hip_lib):
     assert hip_lib.magnet_pack_gmm(None, 16, 1, 4, 4, None) == 1       # MAGNET_E_ALIGN
     assert hip_lib.magnet_gaussian_update(16, 16, 16, 0, 5, None) == 2
     assert hip_lib.magnet_upsample_depth(16, 16, 16, 1, 2, 4, 4, 3, None) == 2  # k must be 1,2,4,8
+    # convolution / F-Net entry points
+    from magnet_amd.lib import MagnetConvArgs, _conv_protos, _fnet_protos
+    _conv_protos(hip_lib); _fnet_protos(hip_lib)
+    c = MagnetConvArgs()
+    assert hip_lib.magnet_conv_mfma(ctypes.byref(c), None) == 1
+    c.in_hi = c.in_lo = c.w_hi = c.w_lo = c.bias = c.out_hi = c.out_lo = 16
+    c.rows, c.cin, c.cout_pad, c.taps, c.wp = 128, 48, 128, 9, 10
+    assert hip_lib.magnet_conv_mfma(ctypes.byref(c), None) == 2                 # cin % 32
+    c.cin = 64; c.cout_pad = 48
+    assert hip_lib.magnet_conv_mfma(ctypes.byref(c), None) == 2                 # unsupported width
+    c.cout_pad = 64; c.taps = 5
+    assert hip_lib.magnet_conv_mfma(ctypes.byref(c), None) == 2                 # taps in {1,4,9}
+    c.taps = 9; c.repad = 1
+    assert hip_lib.magnet_conv_mfma(ctypes.byref(c), None) == 2 and b"repad" in hip_lib.magnet_last_error()
+    c.repad = 0; c.border_hp, c.border_pad = 7, 1                               # 128 rows are not a whole number of 7x10 grids
+    assert hip_lib.magnet_conv_mfma(ctypes.byref(c), None) == 2
+    c.border_hp = 0; c.tail_w_hi = 16
+    assert hip_lib.magnet_conv_mfma(ctypes.byref(c), None) == 1                 # fused tail without its other pointers
+    assert hip_lib.magnet_fnet_stem(None, 16, 16, 16, 16, 1, 8, 8, None) == 1
+    assert hip_lib.magnet_fnet_stem(16, 16, 16, 16, 16, 1, 1, 8, None) == 2
+    assert hip_lib.magnet_space_to_depth(16, 16, 16, 16, 1, 12, 4, 4, 2, None) == 2     # C % 8
+    assert hip_lib.magnet_avgpool_cl(16, 16, 320, 1, 8, 8, 2, 16, 128, 16, 16, None) == 2   # window larger than the map
+    assert hip_lib.magnet_upsample_bilinear_cl(16, 32, 1, 2, 32, 16, 24, 320, 1, 8, 8, 2, None) == 4   # out_lo misaligned
+    assert hip_lib.magnet_cost_volume_f_backward(None, 16, 16, 16, None) == 1
     # D over the limit
     a.ref_feat_cl = a.src_feat_pad = a.src_gmm_pad = a.poses = a.is_valid = a.intM = a.rays = a.cost = 16
     a.d_volume = 16
