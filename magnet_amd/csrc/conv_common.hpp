@@ -17,6 +17,7 @@ struct ConvParams {
     const float* addend;                              // optional fp32 (rows, addend_ld) added before bias/ReLU
     int addend_ld;
     int tap_off[9];                                   // input row offset of each tap (dilation / 2x2 windows: host-computed)
+    int min_off, max_off;                             // min / max of tap_off[0..taps)
     int out_ld;                                       // elements between consecutive output rows (>= cout_pad)
     const uint16_t* add_hi; const uint16_t* add_lo;   // optional split-bf16 addend (residual connections), rows x add_ld
     int add_ld;

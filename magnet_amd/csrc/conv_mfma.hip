@@ -30,7 +30,7 @@ namespace magnet {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-constexpr int CV_BK = 32;
+[[maybe_unused]] constexpr int CV_BK = 32;
 constexpr int CV_ROW = 64;                            // bytes per staged row (32 bf16), unpadded
 
 // LDS image of a [rows][32 bf16] tile: 64-byte rows, the four 16-byte slots of a row XOR-swizzled with
@@ -121,6 +121,7 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
 // TAIL = 0: plain layer.  TAIL = 16-column fragments of the fused tail's last layer (1, 8 or 9): see ConvParams::tail_*.
 template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins do not exist in the host pass (which only needs the stub)
     constexpr int BN = NF * 16;
     constexpr int A_PT = CV_BM / 64;                           // 16-byte vectors per thread per A plane (2 or 4)
     constexpr int WM = 4 / WN;                        // waves along M
@@ -157,38 +158,51 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     // step order: K-chunk outer, tap inner — the 9 taps of one 32-channel chunk re-read (shifted) the same 64-byte
     // row slices back to back, a working set of ~50 KB per workgroup that stays in the XCD's L2; tap-major order
     // swept 164 KB per workgroup between re-reads (x64 resident workgroups >> 4 MiB L2).
-    auto a_elem = [&](int s, int i) -> size_t {
-        const int tap = s % p.taps, k0 = (s / p.taps) * CV_BK;
-        const int off = p.tap_off[tap];
-        long long row = row0 + st_r + i * 64 + off;
-        row = row < 0 ? 0 : (row >= p.rows ? p.rows - 1 : row);        // guard rows only feed border outputs
-        return (size_t)row * p.in_ld + k0 + st_k;
-    };
-    auto b_elem = [&](int s, int i) -> size_t {
-        const int tap = s % p.taps, k0 = (s / p.taps) * CV_BK;
-        return ((size_t)tap * p.cout_pad + n0 + st_r + i * 64) * p.cin + k0 + st_k;
-    };
-    typedef const void __attribute__((address_space(1)))* gptr_t;
+    //
+    // Addressing: buffer descriptors (wave-uniform SGPRs) + one 32-bit per-lane byte offset.  The activation descriptor
+    // covers exactly the row window this workgroup can touch, [row0 + min tap offset, row0 + BM + max tap offset) cut to
+    // [0, rows): a row outside it is out of range for the hardware bounds check and reads as zero — no per-lane
+    // clamping, no 64-bit per-lane arithmetic (the first version spent 137 VALU + 85 SALU instructions per K step
+    // next to 48 MFMAs, mostly on this; such rows only ever feed border / guard outputs).  Per step and DMA piece:
+    // one v_add of a scalar.
+    static_assert(SPB == 1, "the step counters below assume one K stage per barrier interval");
+    long long base_row = row0 + p.min_off;  base_row = base_row < 0 ? 0 : base_row;
+    long long end_row = row0 + CV_BM + p.max_off;  end_row = end_row > p.rows ? p.rows : end_row;
+    const uint32_t flags = 0x00020000u;
+    const __amdgpu_buffer_rsrc_t ra_hi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in_hi + base_row * p.in_ld), 0,
+                                                                           (int)((end_row - base_row) * p.in_ld * 2), flags);
+    const __amdgpu_buffer_rsrc_t ra_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in_lo + base_row * p.in_ld), 0,
+                                                                           (int)((end_row - base_row) * p.in_ld * 2), flags);
+    const int w_bytes = p.taps * p.cout_pad * p.cin * 2;
+    const __amdgpu_buffer_rsrc_t rb_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, w_bytes, flags);
+    const __amdgpu_buffer_rsrc_t rb_lo = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_lo, 0, w_bytes, flags);
+    int a_v[A_PT], b_v[B_PT];                                  // per-lane byte offsets, constant over the K loop
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) a_v[i] = (((int)(row0 - base_row) + st_r + i * 64) * p.in_ld + st_k) * 2;
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) b_v[i] = ((n0 + st_r + i * 64) * p.cin + st_k) * 2;
+    int pf_tap = 0, pf_k0 = 0;                                 // (tap, first channel) of the next stage to fetch
     typedef void __attribute__((address_space(3)))* lptr_t;
-#define CV_GLDS(gp, lp) __builtin_amdgcn_global_load_lds((gptr_t)(gp), (lptr_t)(lp), 16, 0, 0)
+#define CV_BLDS(rsrc, lp, voff) __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lptr_t)(lp), 16, (voff), 0, 0, 0)
 #define CV_DMA(S, BUF)                                                                                 \
     {                                                                                                  \
         unsigned char* sa_hi = smem + (BUF) * STAGE_BYTES;                                             \
         unsigned char* sa_lo = sa_hi + A_BYTES;                                                        \
         unsigned char* sb_hi = sa_hi + 2 * A_BYTES;                                                    \
         unsigned char* sb_lo = sb_hi + B_BYTES;                                                        \
+        const int a_u = (p.tap_off[pf_tap] * p.in_ld + pf_k0) * 2;                                     \
+        const int b_u = (pf_tap * p.cout_pad * p.cin + pf_k0) * 2;                                     \
         _Pragma("unroll") for (int i = 0; i < A_PT; ++i) {                                             \
-            const size_t e = a_elem((S), i);                                                           \
-            CV_GLDS(p.in_hi + e, sa_hi + (wave_row + i * 64) * CV_ROW);                                \
-            CV_GLDS(p.in_lo + e, sa_lo + (wave_row + i * 64) * CV_ROW);                                \
+            CV_BLDS(ra_hi, sa_hi + (wave_row + i * 64) * CV_ROW, a_v[i] + a_u);                        \
+            CV_BLDS(ra_lo, sa_lo + (wave_row + i * 64) * CV_ROW, a_v[i] + a_u);                        \
         }                                                                                              \
         _Pragma("unroll") for (int i = 0; i < B_PT; ++i) {                                             \
             if (st_r + i * 64 < BN) {                                                                  \
-                const size_t e = b_elem((S), i);                                                       \
-                CV_GLDS(p.w_hi + e, sb_hi + (wave_row + i * 64) * CV_ROW);                             \
-                CV_GLDS(p.w_lo + e, sb_lo + (wave_row + i * 64) * CV_ROW);                             \
+                CV_BLDS(rb_hi, sb_hi + (wave_row + i * 64) * CV_ROW, b_v[i] + b_u);                    \
+                CV_BLDS(rb_lo, sb_lo + (wave_row + i * 64) * CV_ROW, b_v[i] + b_u);                    \
             }                                                                                          \
         }                                                                                              \
+        if (++pf_tap == p.taps) { pf_tap = 0; pf_k0 += CV_BK; }                                        \
     }
 
     f32x4_t acc[MF][NFW];
@@ -358,6 +372,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             }
         }
     }
+#endif
 }
 
 template <int NF, int WN, int BM, int SPB>
@@ -397,7 +412,7 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
     if (p.cout_pad == 144) return launch_conv_nf<9, 1, 128, 1>(p, s);
     if (p.cout_pad == 16)  return launch_conv_nf<1, 1, 128, 1>(p, s);
     // F-Net trunk widths: 4 waves stacked along M.  Measured on the whole F-Net (40 images, 23.5 ms): 256-row tiles for
-    // the 32- / 64-wide layers 24.1 / 24.2 ms, 2x2 waves for 64-wide 23.6 ms — no better.
+    // the 32- / 64-wide layers 24.1 / 24.2 ms, 192-row tile for 64-wide 24.6 ms, 2x2 waves for 64-wide 23.6 ms — no better.
     if (p.cout_pad == 32)  return launch_conv_nf<2, 1, 128, 1>(p, s);
     if (p.cout_pad == 64)  return launch_conv_nf<4, 1, 128, 1>(p, s);
     return hipErrorInvalidValue;
@@ -589,6 +604,6 @@ hipError_t launch_pack_split(const float* in, uint16_t* out_hi, uint16_t* out_lo
 }
 
 #undef CV_DMA
-#undef CV_GLDS
+#undef CV_BLDS
 
 }  // namespace magnet
