@@ -17,7 +17,7 @@ inp = device_inputs(wl, B, 1000, dev)
 k = depth_sampling(3, wl.D)
 out = torch.empty(B, wl.D, wl.h, wl.w, device=dev)
 for fdt in ("bf16",):
-    for name, path in (("cand", 2), ("cand noP2", 0x102), ("cand nogmm", 0x202), ("cand noP2 nogmm", 0x302), ("cand geom only", 0x802)):
+    for name, path in (("cand", 2), ("cand noP2", 0x102), ("cand nogmm", 0x202), ("cand noP2 nogmm", 0x302), ("cand geom only", 0x802), ("cand geom only nogmm", 0xA02)):
         cv = CostVolumeCW(inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"], inp["is_valid"],
                           inp["cam_intrins"], 5, feat_dtype=fdt, path=path)
         stats = torch.zeros(4, dtype=torch.int32, device=dev)
