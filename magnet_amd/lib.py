@@ -232,7 +232,8 @@ def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM
     return out
 
 
-def cost_volume_f_backward(ref_feat_cl, src_feat_pad, poses, is_valid, intM, rays, d_center, grad_cost):
+def cost_volume_f_backward(ref_feat_cl, src_feat_pad, poses, is_valid, intM, rays, d_center, grad_cost, path: int = 0,
+                           stats=None):
     """Gradients of the mode-1 volume (est_costvolume_F before its softmax) w.r.t. the two feature maps.
 
     Same tensors as the forward call (fp32 features) + grad_cost (B,D,h,w).  Returns
@@ -256,6 +257,9 @@ def cost_volume_f_backward(ref_feat_cl, src_feat_pad, poses, is_valid, intM, ray
     a.B, a.V, a.F, a.D, a.h, a.w = B, V, F, D, h, w
     a.feat_dtype = FEAT_F32
     a.mode = 1
+    a.path = int(path)                                             # dev: 0x2000 = the per-item atomic kernel
+    if stats is not None:
+        a.stats = _dev(stats, "stats", torch.int32).data_ptr()       # [_, flushed texels, units merged in LDS, units sent to global atomics]
     a.ref_feat_cl, a.src_feat_pad = r.data_ptr(), s.data_ptr()
     kbuf = (ctypes.c_double * D)(*[float(k) for k in d_center])
     a.k_list = ctypes.addressof(kbuf)

@@ -114,3 +114,26 @@ def test_backward_rejects_bad_mode(hip_lib, gpu):
         lib.cost_volume_f_backward(r, torch.zeros(1, 6, 6, 8, device=gpu), torch.eye(4, device=gpu).view(1, 1, 4, 4),
                                    torch.ones(1, 1, dtype=torch.int32, device=gpu), torch.eye(3, device=gpu).view(1, 3, 3),
                                    torch.ones(1, 3, 16, device=gpu), [1.0, 2.0], torch.zeros(1, 3, 4, 4, device=gpu))
+
+
+def test_backward_kernels_agree(hip_lib, gpu):
+    """Tile-privatised backward (LDS hash table, default) vs the per-item atomic kernel (path bit 0x2000) vs the oracle,
+    on a shape with long epipolar runs (table pressure) and an invalid view."""
+    from magnet_amd import lib
+    wl = synth.Workload("f", "scannet", 28, 36, V=3, D=80, F=64)
+    inp = synth.make_inputs(wl, B=2, seed=21, invalid=[(1, 0)])
+    inp["nghbr_poses"][0, 1, :3, 3] = torch.tensor([0.5, 0.1, 0.0])                 # strong lateral parallax
+    dc = _bins(80)
+    gout = torch.randn(2, 80, 28, 36, generator=torch.Generator().manual_seed(6))
+    args = (dc.numpy(), inp["ref_feat"].numpy(), inp["nghbr_feat"].numpy(), inp["nghbr_poses"].numpy(), inp["is_valid"].numpy(),
+            inp["cam_intrins"]["intM"].numpy(), inp["cam_intrins"]["unit_ray_array_2D"].numpy())
+    _, o_gr, o_gs = oracle.cost_volume_f_raw(*args, gout=gout.numpy())
+    ref_cl = lib.pack_features(inp["ref_feat"].to(gpu), lib.FEAT_F32, pad=0); src_pad = lib.pack_features(inp["nghbr_feat"].to(gpu), lib.FEAT_F32, pad=1)
+    bins = [float(v) for v in dc.reshape(-1)]
+    common = (ref_cl, src_pad, inp["nghbr_poses"].to(gpu), inp["is_valid"].int().to(gpu), inp["cam_intrins"]["intM"].to(gpu),
+              inp["cam_intrins"]["unit_ray_array_2D"].to(gpu), bins, gout.to(gpu))
+    for path in (0, 0x2000):
+        gr, gs = lib.cost_volume_f_backward(*common, path=path)
+        gr = gr.permute(0, 3, 1, 2).cpu().numpy(); gs = gs[:, 1:-1, 1:-1].permute(0, 3, 1, 2).cpu().numpy()
+        for got, exp in ((gr, o_gr), (gs, o_gs)):
+            np.testing.assert_allclose(got, exp, rtol=1e-4, atol=2e-5 * max(1.0, float(np.abs(exp).max())))
