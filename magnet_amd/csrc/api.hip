@@ -240,6 +240,7 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
         if (a->wp < 1 || a->border_pad < 0 || a->border_hp <= 2 * a->border_pad || a->wp <= 2 * a->border_pad ||
             (a->rows % ((long long)a->border_hp * a->wp)) != 0)
             return fail(MAGNET_E_DIM, "magnet_conv_mfma: border_hp=%d wp=%d border_pad=%d do not tile rows=%lld", a->border_hp, a->wp, a->border_pad, (long long)a->rows);
+        if ((long long)a->border_hp * a->wp >= (1 << 24)) return fail(MAGNET_E_DIM, "magnet_conv_mfma: border_hp * wp must be < 2^24");
         p.img_rows = a->border_hp * a->wp; p.hp = a->border_hp; p.pad = a->border_pad;
     }
     if (a->repad < 0 || (a->repad && !a->border_hp)) return fail(MAGNET_E_DIM, "magnet_conv_mfma: repad needs border_hp");

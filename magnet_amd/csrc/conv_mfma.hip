@@ -296,6 +296,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 
     // ---- epilogue through LDS, one 16-row fragment per wave at a time: [16 rows][NFW*16] fp32 per wave ----
+    const long long tile_img = p.img_rows ? row0 / p.img_rows : 0;            // wave-uniform (scalar) division, once
+    const int tile_rem = p.img_rows ? (int)(row0 - tile_img * p.img_rows) : 0;
+    const float inv_wp = 1.0f / (float)(p.wp > 0 ? p.wp : 1);
     constexpr int WCOLS = NFW * 16, SROW = WCOLS + 4;          // +4 floats row pad
     float* stage = reinterpret_cast<float*>(smem) + wv * (16 * SROW);
 #pragma unroll
@@ -316,9 +319,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             long long orow = row;
             bool interior = true;
             if (p.img_rows) {                                 // row -> (image, y, x) of the zero-bordered grid
-                const long long img = row / p.img_rows;
-                const int rem = (int)(row - img * p.img_rows);
-                const int y = rem / p.wp, x = rem - y * p.wp;
+                // the tile's first row is decoded once per workgroup on the scalar unit (tile_img, tile_rem); per work item a
+                // 32-bit add, a wrap and a float-reciprocal division by the row pitch (exact: img_rows < 2^24, fixed up)
+                long long img = tile_img;
+                int rem = tile_rem + (int)(row - row0);
+                while (rem >= p.img_rows) { rem -= p.img_rows; ++img; }
+                int y = (int)((float)rem * inv_wp);
+                if (y * p.wp > rem) --y;
+                if ((y + 1) * p.wp <= rem) ++y;
+                const int x = rem - y * p.wp;
                 interior = (y >= p.pad) && (y < p.hp - p.pad) && (x >= p.pad) && (x < p.wp - p.pad);
                 if (p.repad) {
                     if (!interior) continue;
