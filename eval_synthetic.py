@@ -74,6 +74,10 @@ def main():
     ap.add_argument("--input_height", type=int, default=480); ap.add_argument("--input_width", type=int, default=640)
     ap.add_argument("--min_depth", type=float, default=1e-3); ap.add_argument("--max_depth", type=float, default=10.0)
     ap.add_argument("--feat_dtype", default="fp32"); ap.add_argument("--log", default="")
+    ap.add_argument("--dataset_path", default="", help="root of ScanNet-format scene folders (magnet_amd/data.py) instead of synthetic frames")
+    ap.add_argument("--split", default="", help="text file of '<scene> <frame index>' lines (data_split/scannet_*.txt format)")
+    ap.add_argument("--window_radius", type=int, default=20)
+    ap.add_argument("--psmnet", action="store_true", help="use the PSMNet F-Net (matrix-core path) instead of the stub F-Net")
     a = ap.parse_args()
     from tests.stubs import StubDNet, StubFNet, make_args, seeded_magnet_weights
     if not torch.cuda.is_available():
@@ -81,12 +85,27 @@ def main():
     device = torch.device("cuda:0")
     args = make_args(D=a.D, iters=a.iters, dpv_h=a.input_height // 4, dpv_w=a.input_width // 4, V=a.V)
     args.min_depth, args.max_depth = a.min_depth, a.max_depth
-    model = MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2), feat_dtype=a.feat_dtype)
+    f_net = StubFNet(2)
+    if a.psmnet:
+        from magnet_amd.fnet import FNET
+        args.FNET_architecture, args.FNET_feature_dim = "PSM-Net", 64
+        f_net = FNET(args)                                   # random init unless a checkpoint is loaded by the caller
+    model = MAGNET(args, d_net=StubDNet(1), f_net=f_net, feat_dtype=a.feat_dtype)
     seeded_magnet_weights(model, 3)
     model = model.to(device).eval()
-    loader = SyntheticWindows((a.frames + a.batch - 1) // a.batch, a.batch, a.V, a.input_height, a.input_width, nan_every=3)
+    if a.dataset_path:
+        from magnet_amd import data
+        with open(a.split) as f:
+            samples = [ln.split()[:2] for ln in f if ln.strip()]
+        ds = data.ScanNetFolder(a.dataset_path, samples, n_views=a.V, window_radius=a.window_radius,
+                                input_hw=(a.input_height, a.input_width), dpv_hw=(a.input_height // 4, a.input_width // 4))
+        loader = data.batches(ds, a.batch)
+        title = "scannet-format folder %s (%d windows) V=%d D=%d iters=%d" % (a.dataset_path, len(ds), a.V, a.D, a.iters)
+    else:
+        loader = SyntheticWindows((a.frames + a.batch - 1) // a.batch, a.batch, a.V, a.input_height, a.input_width, nan_every=3)
+        title = "synthetic frames=%d V=%d D=%d iters=%d" % (a.frames, a.V, a.D, a.iters)
     m = validate(model, args, loader, device)
-    M.log_metrics(a.log, m, "synthetic frames=%d V=%d D=%d iters=%d" % (a.frames, a.V, a.D, a.iters))
+    M.log_metrics(a.log, m, title)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,150 @@
+"""Dataset-free host side of the path (row N4 of SURVEY.md §8f): camera-intrinsics producer and a loader for
+ScanNet-format scene folders, yielding exactly what the reference's loaders hand to `validate()` /
+`MAGNET.forward` (reference: data/dataloader_scannet.py:16-217, utils/utils.py:64-98).
+
+    <root>/<scene>/color/<i>.jpg   depth/<i>.png (uint16 millimetres)   pose/<i>.txt (4x4 cam->world)
+                   intrinsic/intrinsic_color.txt (4x4)
+
+No torchvision, no dataset split files, no JSON side tables: the raw image size is read from the first colour image
+unless given.  Everything here is host code feeding the device path; nothing is timed by bench.py.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def read_matrix_txt(path: str) -> np.ndarray:
+    """4x4 float64 matrix from a whitespace-separated text file (first four rows)."""
+    m = np.eye(4)
+    with open(path, "r") as f:
+        rows = [ln.split() for ln in f.read().strip().splitlines()[:4]]
+    for i, r in enumerate(rows):
+        m[i, :] = [float(x) for x in r[:4]]
+    return m
+
+
+def read_pose_txt(path: str) -> np.ndarray:
+    """ScanNet stores cam->world; the model wants world->cam (dataloader_scannet.py:16-28).  A lost pose (-inf entries)
+    inverts to NaN, which `preprocess.data_preprocess` turns into is_valid = 0, like the reference (utils.py:84-94)."""
+    with np.errstate(all="ignore"):
+        try:
+            return np.linalg.inv(read_matrix_txt(path))
+        except np.linalg.LinAlgError:
+            return np.full((4, 4), np.nan)
+
+
+def cam_intrinsics(K: np.ndarray, raw_w: int, raw_h: int, dpv_h: int, dpv_w: int) -> dict:
+    """K (>=3x3, pixels of the raw_w x raw_h image) -> {'intM' (3,3), 'unit_ray_array_2D' (3, dpv_h*dpv_w)} fp32:
+    intrinsics scaled to the matching grid and the ray ((x+0.5)*sx - cx)/fx, ((y+0.5)*sy - cy)/fy, 1 of every grid pixel,
+    row-major (dataloader_scannet.py:113-153; float64 math, one cast)."""
+    K = np.asarray(K, dtype=np.float64)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    intM = np.zeros((3, 3))
+    intM[2, 2] = 1.0
+    intM[0, 0], intM[1, 1] = fx * (dpv_w / raw_w), fy * (dpv_h / raw_h)
+    intM[0, 2], intM[1, 2] = cx * (dpv_w / raw_w), cy * (dpv_h / raw_h)
+    xs = np.arange(dpv_w, dtype=np.float64)[None, :] + 0.5
+    ys = np.arange(dpv_h, dtype=np.float64)[:, None] + 0.5
+    rays = np.ones((3, dpv_h, dpv_w))
+    rays[0] = (xs * (raw_w / dpv_w) - cx) / fx
+    rays[1] = (ys * (raw_h / dpv_h) - cy) / fy
+    return {"intM": torch.from_numpy(intM.astype(np.float32)),
+            "unit_ray_array_2D": torch.from_numpy(rays.reshape(3, -1).astype(np.float32))}
+
+
+def window_indices(center: int, n_views: int, window_radius: int, exists) -> list:
+    """Frame indices of the local window, reference frame in the middle (dataloader_scannet.py:81-89,160-165): offsets
+    k * (radius // (n_views // 2)), k = -n/2..n/2; a missing neighbour is mirrored to the other side, half a step closer."""
+    step = window_radius // (n_views // 2)
+    out = []
+    for k in range(-(n_views // 2), n_views // 2 + 1):
+        off = k * step
+        if exists(center + off):
+            out.append(center + off)
+        else:
+            out.append(center - off - int(np.sign(off)) * int(step * 0.5))
+    return out
+
+
+class ScanNetFolder:
+    """samples: list of (scene_name, frame_index).  __getitem__ -> (data_array, cam_intrins): a list of n_views + 1 dicts
+    {'img' (3,H,W) normalised fp32, 'gt_dmap' (1,H,W) metres for the reference frame else 0.0, 'extM' (4,4) float64,
+    'scene_name', 'img_idx'} and the intrinsics dict — the structure of dataloader_scannet.py:155-217."""
+
+    def __init__(self, root, samples, n_views=4, window_radius=20, input_hw=(480, 640), dpv_hw=(120, 160), raw_wh=None):
+        from PIL import Image  # noqa: F401  (fail early if Pillow is missing)
+        self.root, self.samples = root, list(samples)
+        self.n_views, self.window_radius = n_views, window_radius
+        self.img_h, self.img_w = input_hw
+        self.dpv_h, self.dpv_w = dpv_hw
+        self.raw_wh = dict(raw_wh or {})
+        self.center = n_views // 2
+
+    def __len__(self):
+        return len(self.samples)
+
+    def _scene(self, name):
+        return os.path.join(self.root, name)
+
+    def _raw_wh(self, scene, any_idx):
+        if scene not in self.raw_wh:
+            from PIL import Image
+            with Image.open(os.path.join(self._scene(scene), "color", f"{any_idx}.jpg")) as im:
+                self.raw_wh[scene] = im.size                                   # (W, H)
+        return self.raw_wh[scene]
+
+    def __getitem__(self, i):
+        from PIL import Image
+        scene, idx = self.samples[i]
+        idx = int(idx)
+        sdir = self._scene(scene)
+        frames = window_indices(idx, self.n_views, self.window_radius,
+                                lambda k: os.path.exists(os.path.join(sdir, "color", f"{k}.jpg")))
+        raw_w, raw_h = self._raw_wh(scene, idx)
+        intr = cam_intrinsics(read_matrix_txt(os.path.join(sdir, "intrinsic", "intrinsic_color.txt")), raw_w, raw_h,
+                              self.dpv_h, self.dpv_w)
+        mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1); std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
+        data_array = []
+        for j, k in enumerate(frames):
+            with Image.open(os.path.join(sdir, "color", f"{k}.jpg")) as im:
+                rgb = im.convert("RGB").resize((self.img_w, self.img_h), resample=Image.BILINEAR)
+            img = torch.from_numpy(np.asarray(rgb).astype(np.float32) / 255.0).permute(2, 0, 1)
+            img = (img - mean) / std
+            if j == self.center:
+                with Image.open(os.path.join(sdir, "depth", f"{k}.png")) as dm:
+                    d = np.asarray(dm.resize((self.img_w, self.img_h), resample=Image.NEAREST)).astype(np.float32) / 1000.0
+                gt = torch.from_numpy(d)[None]
+            else:
+                gt = 0.0
+            data_array.append({"img": img, "gt_dmap": gt, "extM": read_pose_txt(os.path.join(sdir, "pose", f"{k}.txt")),
+                               "scene_name": scene, "img_idx": str(k)})
+        return data_array, intr
+
+
+def collate(items):
+    """What torch's default_collate makes of a list of (data_array, cam_intrins): per-frame dicts with a leading batch
+    dimension ('extM' becomes a (B,4,4) float64 tensor), intrinsics stacked to (B,3,3) / (B,3,hw)."""
+    n_frames = len(items[0][0])
+    data_array = []
+    for f in range(n_frames):
+        ds = [it[0][f] for it in items]
+        gt = ds[0]["gt_dmap"]
+        data_array.append({
+            "img": torch.stack([d["img"] for d in ds]),
+            "gt_dmap": torch.stack([d["gt_dmap"] for d in ds]) if torch.is_tensor(gt) else torch.zeros(len(ds), dtype=torch.float64),
+            "extM": torch.from_numpy(np.stack([d["extM"] for d in ds])),
+            "scene_name": [d["scene_name"] for d in ds], "img_idx": [d["img_idx"] for d in ds]})
+    intr = {k: torch.stack([it[1][k] for it in items]) for k in items[0][1]}
+    return data_array, intr
+
+
+def batches(dataset, batch_size=1):
+    """Sequential batches of (data_array, cam_intrins), the iteration protocol of the reference's test loaders."""
+    for s in range(0, len(dataset), batch_size):
+        yield collate([dataset[i] for i in range(s, min(s + batch_size, len(dataset)))])
