@@ -238,8 +238,12 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 const int passes = (p.ablate & 1) ? 0 : (nitems + 1) >> 1;        // 2 items (8 units) per pass
                 for (int ps = 0; ps < passes; ps += 2) {
                     uint4 sv[2][CPL], rv[2][CPL];
+                    // second pass of the pair only if it holds an item (wave-uniform): at ~3.5 items per (pixel, view) a third of
+                    // the iterations need one pass
+                    const bool second = (2 * (ps + 1) < nitems) || (p.ablate & 32);
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
+                        if (a == 1 && !second) break;
                         const int it = min(2 * (ps + a) + upair, nitems);         // tail of an odd pass pair: the pad item
                         const uint32_t item = items[it];
                         const unsigned char* sp = src + (__umul24(item & 0xffffffu, texel_bytes) + lane_src_off);
@@ -255,6 +259,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                     }
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
+                        if (a == 1 && !second) break;
                         float part = 0.f;
 #pragma unroll
                         for (int cc = 0; cc < CPL; ++cc) part = cdot_chunk(rv[a][cc], sv[a][cc], part, FeatT());
