@@ -120,6 +120,14 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
     for (int v = 0; v < p.V; ++v) vmask |= (unsigned long long)(p.is_valid[b * p.V + v] == 1) << v;
     vmask = __builtin_amdgcn_readfirstlane((uint32_t)vmask) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(vmask >> 32)) << 32);
     CGmmPair g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};              // tap registers (only leader lanes' values are ever read)
+    // (mu, sigma) of the wave's 16 reference pixels, lane q holds pixel q: read once per wave instead of a dependent global
+    // load at the head of every pixel's view loop
+    float mu_row = 0.f, sg_row = 0.f;
+    if (!p.d_volume && !p.mode_f) {
+        const size_t pixr = (size_t)yc * p.w + min(x_base + (lane & 15), p.w - 1);
+        mu_row = p.ref_gmm[((size_t)b * 2 + 0) * hw + pixr];
+        sg_row = p.ref_gmm[((size_t)b * 2 + 1) * hw + pixr];
+    }
 
     for (int jb = 0; jb < JB; ++jb) {                                             // candidate block of DL candidates
         const int j = jb * DL + j0;
@@ -145,8 +153,8 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
             if (p.d_volume) d = p.d_volume[((size_t)b * p.D + jc) * hw + pix];
             else if (p.mode_f) d = kj;                                            // fixed depth bin (homography.py:54)
             else {
-                const float mu = p.ref_gmm[((size_t)b * 2 + 0) * hw + pix];
-                const float sg = p.ref_gmm[((size_t)b * 2 + 1) * hw + pix];
+                const float mu = __shfl(mu_row, q);
+                const float sg = __shfl(sg_row, q);
                 const float sk = sg * kj; d = mu + sk;                            // MAGNET.py:155 (mul, then add)
             }
             d = live ? d : __builtin_nanf("");                                    // dead lane -> out of image below
