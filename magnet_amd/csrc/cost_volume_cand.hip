@@ -64,8 +64,8 @@ constexpr uint32_t KEY_CLOSED = 0xffffffffu;
 
 // DL   = candidates per pixel group inside a wave (8,16,32,64); PPW = 64/DL pixels per iteration
 // CPL  = 16-byte channel chunks per lane in the correlation (F*sizeof(FeatT)/16 <= 8*CPL), FULL = exactly
-// MINW = waves per SIMD to compile for
-template <typename FeatT, int DL, int CPL, bool FULL, int MINW>
+// MINW = waves per SIMD to compile for; MODEF = est_costvolume_F semantics (CvParams::mode_f) as a compile-time constant
+template <typename FeatT, int DL, int CPL, bool FULL, int MINW, bool MODEF>
 __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
     constexpr int PPW = 64 / DL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
     // (mu, sigma) of the wave's 16 reference pixels, lane q holds pixel q: read once per wave instead of a dependent global
     // load at the head of every pixel's view loop
     float mu_row = 0.f, sg_row = 0.f;
-    if (!p.d_volume && !p.mode_f) {
+    if (!p.d_volume && !MODEF) {
         const size_t pixr = (size_t)yc * p.w + min(x_base + (lane & 15), p.w - 1);
         mu_row = p.ref_gmm[((size_t)b * 2 + 0) * hw + pixr];
         sg_row = p.ref_gmm[((size_t)b * 2 + 1) * hw + pixr];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
             }
             float d;
             if (p.d_volume) d = p.d_volume[((size_t)b * p.D + jc) * hw + pix];
-            else if (p.mode_f) d = kj;                                            // fixed depth bin (homography.py:54)
+            else if (MODEF) d = kj;                                            // fixed depth bin (homography.py:54)
             else {
                 const float mu = __shfl(mu_row, q);
                 const float sg = __shfl(sg_row, q);
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)KEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);  // wave_shr:1
                 if (j0 == 0) tprev = KEY_CLOSED;                                  // first candidate of a pixel group
                 const bool lead = inwin && (tkey != tprev);
-                if (lead && !(p.ablate & 2) && !p.mode_f) {
+                if (lead && !(p.ablate & 2) && !MODEF) {
                     g0 = *reinterpret_cast<const CGmmPair*>(sgm + qi * 8u);
                     g1 = *reinterpret_cast<const CGmmPair*>(sgm + (qi + (uint32_t)Wp) * 8u);
                 }
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                     gate = inwin && (__builtin_fabsf(zw - mu_w) < sg_w * p.kappa);    // homography.py:157-158
                     if (p.ablate & 2) gate = inwin && ((j0 & 3) != 0);                // dev: taps skipped, ~75 % open
                     if (p.ablate & 8) gate = false;                                   // dev: geometry only
-                    if (p.mode_f) gate = inwin;                                       // est_costvolume_F has no gate
+                    if (MODEF) gate = inwin;                                       // est_costvolume_F has no gate
                 };
                 const bool spec = (p.ablate & 16) && !(p.ablate & 8);
                 if (!spec) eval_gate();
@@ -283,11 +283,11 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 if (gate) {
                     const float4 c4 = *reinterpret_cast<const float4*>(ctab + myitem * 4);
                     const float c = bilerp(c4.x, c4.y, c4.z, c4.w, t);
-                    if (p.mode_f) accf = accf + c; else acc += (double)c;         // homography.py:42 / :159,116
+                    if (MODEF) accf = accf + c; else acc += (double)c;         // homography.py:42 / :159,116
                 }
                 wave_lds_fence();                                                 // ctab/items are rewritten by the next view
             }
-            const float cval = (p.mode_f ? accf : (float)acc) / fV;               // homography.py:46 / :118,120
+            const float cval = (MODEF ? accf : (float)acc) / fV;               // homography.py:46 / :118,120
             if (p.cost_hi) {
                 // split-bf16 channel-last output for the conv kernel: lanes = consecutive channels of one row
                 if (live) {
@@ -324,7 +324,8 @@ static size_t cand_lds_bytes(const CvParams& p) { return (size_t)4 * (p.V * 512 
 template <typename FeatT, int DL, int CPL, bool FULL, int MINW>
 static hipError_t launch_cand(const CvParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
-    hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW>), grid, block, cand_lds_bytes<DL>(p), stream, p);
+    if (p.mode_f) hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, true>), grid, block, cand_lds_bytes<DL>(p), stream, p);
+    else          hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, false>), grid, block, cand_lds_bytes<DL>(p), stream, p);
     return hipGetLastError();
 }
 
