@@ -64,9 +64,15 @@ constexpr uint32_t KEY_CLOSED = 0xffffffffu;
 
 // DL   = candidates per pixel group inside a wave (8,16,32,64); PPW = 64/DL pixels per iteration
 // CPL  = 16-byte channel chunks per lane in the correlation (F*sizeof(FeatT)/16 <= 8*CPL), FULL = exactly
-// MINW = waves per SIMD to compile for; MODEF = est_costvolume_F semantics (CvParams::mode_f) as a compile-time constant
-template <typename FeatT, int DL, int CPL, bool FULL, int MINW, bool MODEF>
+// MINW = waves per SIMD to compile for; VAR = compile-time specialisation: 0 generic matcher (run-time options), 1 est_costvolume_F
+// mode, 2 production matcher (candidates sampled in-kernel, no stats counters, no dev ablations): fewer scalar tests and live registers
+template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int VAR>
 __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
+    constexpr bool MODEF = VAR == 1;                      // est_costvolume_F semantics
+    constexpr bool FASTV = VAR == 2;                      // production matcher: sampled candidates, no stats, no dev ablations
+    const int abl = FASTV ? 0 : p.ablate;
+    uint32_t* const stats = FASTV ? nullptr : p.stats;
+    const float* const d_volume = FASTV ? nullptr : p.d_volume;
     constexpr int PPW = 64 / DL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
     // (mu, sigma) of the wave's 16 reference pixels, lane q holds pixel q: read once per wave instead of a dependent global
     // load at the head of every pixel's view loop
     float mu_row = 0.f, sg_row = 0.f;
-    if (!p.d_volume && !MODEF) {
+    if (!d_volume && !MODEF) {
         const size_t pixr = (size_t)yc * p.w + min(x_base + (lane & 15), p.w - 1);
         mu_row = p.ref_gmm[((size_t)b * 2 + 0) * hw + pixr];
         sg_row = p.ref_gmm[((size_t)b * 2 + 1) * hw + pixr];
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
     for (int jb = 0; jb < JB; ++jb) {                                             // candidate block of DL candidates
         const int j = jb * DL + j0;
         const int jc = min(j, p.D - 1);
-        const float kj = p.d_volume ? 0.f : p.k[jc];
+        const float kj = d_volume ? 0.f : p.k[jc];
         for (int qb = 0; qb < 16 / PPW; ++qb) {
             const int q = qb * PPW + g;                                           // pixel within the wave's row
             const int x = x_base + q;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                                                                 : make_uint4(0, 0, 0, 0);
             }
             float d;
-            if (p.d_volume) d = p.d_volume[((size_t)b * p.D + jc) * hw + pix];
+            if (d_volume) d = d_volume[((size_t)b * p.D + jc) * hw + pix];
             else if (MODEF) d = kj;                                            // fixed depth bin (homography.py:54)
             else {
                 const float mu = __shfl(mu_row, q);
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)KEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);  // wave_shr:1
                 if (j0 == 0) tprev = KEY_CLOSED;                                  // first candidate of a pixel group
                 const bool lead = inwin && (tkey != tprev);
-                if (lead && !(p.ablate & 2) && !MODEF) {
+                if (lead && !(abl & 2) && !MODEF) {
                     g0 = *reinterpret_cast<const CGmmPair*>(sgm + qi * 8u);
                     g1 = *reinterpret_cast<const CGmmPair*>(sgm + (qi + (uint32_t)Wp) * 8u);
                 }
@@ -218,11 +224,11 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                     const float mu_w = bilerp(g0.mu0, g0.mu1, g1.mu0, g1.mu1, t);
                     const float sg_w = bilerp(g0.sg0, g0.sg1, g1.sg0, g1.sg1, t);
                     gate = inwin && (__builtin_fabsf(zw - mu_w) < sg_w * p.kappa);    // homography.py:157-158
-                    if (p.ablate & 2) gate = inwin && ((j0 & 3) != 0);                // dev: taps skipped, ~75 % open
-                    if (p.ablate & 8) gate = false;                                   // dev: geometry only
+                    if (abl & 2) gate = inwin && ((j0 & 3) != 0);                // dev: taps skipped, ~75 % open
+                    if (abl & 8) gate = false;                                   // dev: geometry only
                     if (MODEF) gate = inwin;                                       // est_costvolume_F has no gate
                 };
-                const bool spec = (p.ablate & 16) && !(p.ablate & 8);
+                const bool spec = (abl & 16) && !(abl & 8);
                 if (!spec) eval_gate();
                 const bool open = spec ? inwin : gate;                               // lanes whose quad becomes an item
 
@@ -239,16 +245,16 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 const int myitem = below + (fresh ? 1 : 0) - 1;                  // the item covering this lane (if open)
                 if (fresh) items[below] = ((uint32_t)q << 26) | qi;
                 if (lane == 0) items[nitems] = 0u;                                // pad to a whole pass: pixel 0, texel 0
-                if (p.stats && lane == 0) atomicAdd(p.stats + 2, (unsigned)nitems);
+                if (stats && lane == 0) atomicAdd(stats + 2, (unsigned)nitems);
                 wave_lds_fence();
 
                 // ---------------- correlation: unit = (item, tap), 8 lanes x 16 B per unit ----------------
-                const int passes = (p.ablate & 1) ? 0 : (nitems + 1) >> 1;        // 2 items (8 units) per pass
+                const int passes = (abl & 1) ? 0 : (nitems + 1) >> 1;        // 2 items (8 units) per pass
                 for (int ps = 0; ps < passes; ps += 2) {
                     uint4 sv[2][CPL], rv[2][CPL];
                     // second pass of the pair only if it holds an item (wave-uniform): at ~3.5 items per (pixel, view) a third of
                     // the iterations need one pass
-                    const bool second = (2 * (ps + 1) < nitems) || (p.ablate & 32);
+                    const bool second = (2 * (ps + 1) < nitems) || (abl & 32);
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
                         if (a == 1 && !second) break;
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
             }
         }
     }
-    if (p.stats && tid == 0) atomicAdd(p.stats + 0, 1u);
+    if (stats && tid == 0) atomicAdd(stats + 0, 1u);
 }
 
 template <int DL>
@@ -324,8 +330,10 @@ static size_t cand_lds_bytes(const CvParams& p) { return (size_t)4 * (p.V * 512 
 template <typename FeatT, int DL, int CPL, bool FULL, int MINW>
 static hipError_t launch_cand(const CvParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
-    if (p.mode_f) hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, true>), grid, block, cand_lds_bytes<DL>(p), stream, p);
-    else          hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, false>), grid, block, cand_lds_bytes<DL>(p), stream, p);
+    if (p.mode_f) hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 1>), grid, block, cand_lds_bytes<DL>(p), stream, p);
+    else if (!p.d_volume && !p.stats && !p.ablate)
+        hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 2>), grid, block, cand_lds_bytes<DL>(p), stream, p);
+    else hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 0>), grid, block, cand_lds_bytes<DL>(p), stream, p);
     return hipGetLastError();
 }
 
