@@ -342,6 +342,8 @@ static hipError_t launch_cand_c(const CvParams& p, hipStream_t stream) {
     if (p.D <= 8)       return launch_cand<FeatT, 8, CPL, FULL, 4>(p, stream);
     else if (p.D <= 16) return launch_cand<FeatT, 16, CPL, FULL, 4>(p, stream);
     else if (p.D <= 32) return launch_cand<FeatT, 32, CPL, FULL, 4>(p, stream);
+    // fp32 features carry twice the chunk registers: 6 waves/SIMD spills 76 B/lane there, 5 does not
+    if (sizeof(FeatT) == 4) return launch_cand<FeatT, 64, CPL, FULL, 5>(p, stream);
     return launch_cand<FeatT, 64, CPL, FULL, 6>(p, stream);
 }
 
