@@ -227,6 +227,10 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     const int dil = a->dil > 1 ? a->dil : 1;
     if (a->taps == 9) for (int t = 0; t < 9; ++t) p.tap_off[t] = ((t / 3 - 1) * a->wp + (t % 3 - 1)) * dil;
     if (a->taps == 4) { p.tap_off[0] = -a->wp - 1; p.tap_off[1] = -a->wp; p.tap_off[2] = -1; p.tap_off[3] = 0; }
+    p.tap_n = a->taps == 9 ? 3 : (a->taps == 4 ? 2 : 1);
+    p.tap_o0 = a->taps == 1 ? 0 : -1;
+    p.tap_sy = a->taps == 9 ? a->wp * dil : (a->taps == 4 ? a->wp : 0);
+    p.tap_sx = a->taps == 9 ? dil : (a->taps == 4 ? 1 : 0);
     for (int t = 0; t < a->taps; ++t) { p.min_off = p.tap_off[t] < p.min_off ? p.tap_off[t] : p.min_off; p.max_off = p.tap_off[t] > p.max_off ? p.tap_off[t] : p.max_off; }
     if (((long long)128 + p.max_off - p.min_off + 256) * (long long)p.in_ld * 2 >= ((long long)1 << 31) || (long long)a->taps * a->cout_pad * a->cin * 2 >= ((long long)1 << 31))
         return fail(MAGNET_E_DIM, "magnet_conv_mfma: row window or weight tensor exceeds 2 GiB");

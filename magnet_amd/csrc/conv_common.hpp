@@ -18,6 +18,8 @@ struct ConvParams {
     int addend_ld;
     int tap_off[9];                                   // input row offset of each tap (dilation / 2x2 windows: host-computed)
     int min_off, max_off;                             // min / max of tap_off[0..taps)
+    int tap_n, tap_o0, tap_sy, tap_sx;                // taps = tap_n^2; offset of tap (ty,tx) = (ty+o0)*sy + (tx+o0)*sx — the kernel
+                                                      // steps (ty,tx) with scalar counters instead of loading tap_off[] per K step
     int out_ld;                                       // elements between consecutive output rows (>= cout_pad)
     const uint16_t* add_hi; const uint16_t* add_lo;   // optional split-bf16 addend (residual connections), rows x add_ld
     int add_ld;

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     for (int i = 0; i < A_PT; ++i) a_v[i] = (((int)(row0 - base_row) + st_r + i * 64) * p.in_ld + st_k) * 2;
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) b_v[i] = ((n0 + st_r + i * 64) * p.cin + st_k) * 2;
-    int pf_tap = 0, pf_k0 = 0;                                 // (tap, first channel) of the next stage to fetch
+    int pf_tap = 0, pf_ty = 0, pf_tx = 0, pf_k0 = 0;           // (tap = ty*n+tx, first channel) of the next stage to fetch
     typedef void __attribute__((address_space(3)))* lptr_t;
 #define CV_BLDS(rsrc, lp, voff) __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lptr_t)(lp), 16, (voff), 0, 0, 0)
 #define CV_DMA(S, BUF)                                                                                 \
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         unsigned char* sa_lo = sa_hi + A_BYTES;                                                        \
         unsigned char* sb_hi = sa_hi + 2 * A_BYTES;                                                    \
         unsigned char* sb_lo = sb_hi + B_BYTES;                                                        \
-        const int a_u = (p.tap_off[pf_tap] * p.in_ld + pf_k0) * 2;                                     \
+        const int a_u = (((pf_ty + p.tap_o0) * p.tap_sy + (pf_tx + p.tap_o0) * p.tap_sx) * p.in_ld + pf_k0) * 2;    \
         const int b_u = (pf_tap * p.cout_pad * p.cin + pf_k0) * 2;                                     \
         _Pragma("unroll") for (int i = 0; i < A_PT; ++i) {                                             \
             CV_BLDS(ra_hi, sa_hi + (wave_row + i * 64) * CV_ROW, a_v[i] + a_u);                        \
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                 CV_BLDS(rb_lo, sb_lo + (wave_row + i * 64) * CV_ROW, b_v[i] + b_u);                    \
             }                                                                                          \
         }                                                                                              \
-        if (++pf_tap == p.taps) { pf_tap = 0; pf_k0 += CV_BK; }                                        \
+        ++pf_tap;                                                                                      \
+        if (++pf_tx == p.tap_n) { pf_tx = 0; if (++pf_ty == p.tap_n) { pf_ty = 0; pf_tap = 0; pf_k0 += CV_BK; } }   \
     }
 
     f32x4_t acc[MF][NFW];
