@@ -303,14 +303,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int WCOLS = NFW * 16, SROW = WCOLS + 4;          // +4 floats row pad
     float* stage = reinterpret_cast<float*>(smem) + wv * (16 * SROW);
 #pragma unroll
+    // the staging rows are wave-private: after the K loop's final barrier (every wave is done with the ring) only the
+    // wave's own LDS accesses need ordering — in-order in hardware, a scheduling fence for the compiler — no workgroup barrier
     for (int m = 0; m < MF; ++m) {                            // fully unrolled: acc indices stay static
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int n = 0; n < NFW; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 stage[((lane >> 4) * 4 + r) * SROW + n * 16 + (lane & 15)] = acc[m][n][r];   // C: col = lane&15, row = (lane>>4)*4+r
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // 16 rows x WCOLS channels, 8 channels (one 16-byte bf16 vector / two fp32 vectors) per work item
         for (int it = lane; it < 16 * (WCOLS / 8); it += 64) {
             const int r = it / (WCOLS / 8), c8 = (it % (WCOLS / 8)) * 8;
