@@ -177,3 +177,19 @@ def test_magnet_with_fnet_mfma(hip_lib, gpu):
     rel = ((a - b).abs() / b.abs().clamp_min(1e-3)).mean().item()
     print(f"MAGNET with F-Net on MFMA vs torch F-Net: mean |d mu|/mu = {rel:.2e}")
     assert rel < 2e-5
+
+
+@pytest.mark.parametrize("hw", [(352, 1216), (258, 330), (480, 640)])
+def test_fnet_mfma_shapes_vs_torch(hip_lib, gpu, hw):
+    """KITTI / odd (H/2 = 129, W/2 = 165: the space-to-depth phases run past the edge) / ScanNet input sizes against the same
+    module's torch forward on the GPU (MIOpen fp32)."""
+    H, W = hw
+    m = seeded_fnet_state(fnet.PSMNet(feature_dim=64), seed=7).eval().to(gpu)
+    img = procedural_images(2, H, W).to(gpu)
+    with torch.no_grad():
+        ref = m(img)
+    out = fnet.FNetMFMA(m).run(img)
+    assert out.shape == ref.shape
+    err = ((out - ref).abs().max() / ref.abs().max()).item()
+    print(f"F-Net {H}x{W}: max err / max|feat| = {err:.2e}")
+    assert err < 2e-4
