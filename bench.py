@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--conv-backend", default="mfma", choices=["mfma", "torch"],
                     help="g_net/mask_head convolutions: bf16x3 MFMA kernel (default) or nn.Conv2d on MIOpen")
     ap.add_argument("--no-fuse-tail", action="store_true", help="one launch per 1x1 layer instead of the fused epilogue")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph (magnet_amd/graph.py; small batches)")
     ap.add_argument("--overlap", action="store_true", help="run the mask head on a side stream (measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-only", action="store_true", help="step = the fused cost-volume kernel alone")
@@ -174,6 +175,13 @@ def main():
         def step(timed):
             CostVolumeCW.event_sink = ev_pairs if timed else None   # HIP events around the fused kernel
             matcher(ref_gmm=inp["ref_gmms"], k_list=k_list, out=out)
+    elif a.graph:
+        from magnet_amd.graph import GraphedRefine
+        graphed = GraphedRefine(model, inp["ref_gmms"], inp["x_d3"], inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"],
+                                inp["nghbr_poses"], inp["is_valid"], inp["cam_intrins"], mode="test")
+
+        def step(timed):
+            graphed(*graphed.static)                        # inputs already in place: replay only
     else:
         def step(timed):
             CostVolumeCW.event_sink = ev_pairs if timed else None

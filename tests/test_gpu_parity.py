@@ -366,3 +366,28 @@ def test_hoisted_invariant_conv_matches_unhoisted(hip_lib, gpu):
         for a, b in zip(*outs):
             assert torch.isfinite(a).all()
             assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), (D, (a - b).abs().max().item())
+
+
+def test_graph_replay_matches_eager(hip_lib, gpu):
+    """HIP-graph capture of the refinement loop (magnet_amd/graph.py): replays with new inputs, validity and poses equal eager runs."""
+    from magnet_amd.graph import GraphedRefine
+    from magnet_amd.magnet import MAGNET
+    args = make_args(D=16, iters=2, dpv_h=24, dpv_w=32, V=3)
+    model = MAGNET(args, d_net=StubDNet(0), f_net=StubFNet(1), feat_dtype="bf16").to(gpu).eval()
+    seeded_magnet_weights(model, seed=2)
+    wl = synth.Workload("g", "scannet", 24, 32, V=3, D=16, F=64)
+
+    def inputs(seed, invalid):
+        inp = to_dev(synth.make_inputs(wl, B=2, seed=seed, invalid=invalid), gpu)
+        x_d3 = torch.randn(2, 256, 24, 32, generator=torch.Generator().manual_seed(seed)).to(gpu) * 0.5
+        return inp, (inp["ref_gmms"], x_d3, inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"])
+
+    inp0, t0 = inputs(1, ())
+    g = GraphedRefine(model, *t0, inp0["is_valid"], inp0["cam_intrins"])
+    for seed, invalid in ((1, ()), (5, [(1, 2)]), (9, [(0, 0), (1, 1)])):
+        inp, t = inputs(seed, invalid)
+        with torch.no_grad():
+            eager = [o.clone() for o in model.match_and_refine(*t, inp["is_valid"], inp["cam_intrins"], mode="test")]
+        got = g(*t, is_valid=inp["is_valid"], cam_intrins=inp["cam_intrins"])
+        torch.cuda.synchronize()
+        assert len(got) == len(eager) and all(torch.equal(a, b) for a, b in zip(got, eager))
