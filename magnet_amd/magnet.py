@@ -269,8 +269,8 @@ class MAGNET(nn.Module):
 
     def _fnet_runner(self):
         """FNetMFMA for a PSMNet-structured F-Net (ours or the reference's own class) when conv_backend == 'mfma'."""
-        if self.conv_backend != "mfma" or not self.fnet_mfma:
-            return None
+        if self.conv_backend != "mfma" or not self.fnet_mfma or self.f_net.training:
+            return None            # BatchNorm in training mode cannot be folded: the module's own forward runs (reference semantics)
         if self._fnet is None:
             from .fnet import FNetMFMA
             psm = getattr(self.f_net, "f_net", self.f_net)
