@@ -391,3 +391,29 @@ def test_graph_replay_matches_eager(hip_lib, gpu):
         got = g(*t, is_valid=inp["is_valid"], cam_intrins=inp["cam_intrins"])
         torch.cuda.synchronize()
         assert len(got) == len(eager) and all(torch.equal(a, b) for a, b in zip(got, eager))
+
+
+def test_cost_volume_bench_size_batch_invariance(hip_lib, gpu):
+    """BASELINE full size (C2, 64 frames per launch, bf16 features — the bench.py launch): frames of the batched launch equal
+    the same frames launched alone (bitwise: no cross-frame state, no 32-bit offset overflow at 6 GB of inputs), and three of them
+    are checked against the oracle."""
+    wl = synth.WORKLOADS["C2"]
+    B = 64
+    inp = synth.make_inputs(wl, B=B, seed=123, round_bf16=True)
+    k = oracle.depth_sampling(3, wl.D)
+    full = _hip_cost(inp, k, gpu, feat_dtype="bf16", path=0)
+    V = wl.V
+
+    def frame(b):
+        sel = lambda t: t[b:b + 1].contiguous()
+        nb = inp["nghbr_feat"].view(V, B, *inp["nghbr_feat"].shape[1:])[:, b:b + 1].reshape(V, *inp["nghbr_feat"].shape[1:]).contiguous()
+        ng = inp["nghbr_gmms"].view(V, B, *inp["nghbr_gmms"].shape[1:])[:, b:b + 1].reshape(V, *inp["nghbr_gmms"].shape[1:]).contiguous()
+        return dict(ref_feat=sel(inp["ref_feat"]), nghbr_feat=nb, ref_gmms=sel(inp["ref_gmms"]), nghbr_gmms=ng,
+                    nghbr_poses=sel(inp["nghbr_poses"]), is_valid=sel(inp["is_valid"]),
+                    cam_intrins={kk: sel(v) for kk, v in inp["cam_intrins"].items()})
+
+    for b in (0, 31, 63):
+        one = frame(b)
+        alone = _hip_cost(one, k, gpu, feat_dtype="bf16", path=0)
+        assert torch.equal(alone[0], full[b]), f"frame {b}: batched launch differs from the single-frame launch"
+        assert_cost_parity(alone, oracle_cost(one, k), path=0, label=f"C2 bench-size frame {b}")
