@@ -417,3 +417,28 @@ def test_cost_volume_bench_size_batch_invariance(hip_lib, gpu):
         alone = _hip_cost(one, k, gpu, feat_dtype="bf16", path=0)
         assert torch.equal(alone[0], full[b]), f"frame {b}: batched launch differs from the single-frame launch"
         assert_cost_parity(alone, oracle_cost(one, k), path=0, label=f"C2 bench-size frame {b}")
+
+
+def test_full_step_bench_size_batch_invariance(hip_lib, gpu):
+    """The whole C2 step at the bench.py batch (64 frames: 1.26 M activation rows per convolution launch) gives, frame by frame,
+    exactly what a single-frame step gives: the matcher, the matrix-core stacks with their fused tails, update and upsampling."""
+    from magnet_amd.magnet import MAGNET
+    wl = synth.WORKLOADS["C2"]
+    B = 64
+    args = make_args(D=wl.D, iters=1, dpv_h=wl.h, dpv_w=wl.w, V=wl.V)
+    model = MAGNET(args, d_net=StubDNet(0), f_net=StubFNet(1), feat_dtype="bf16").to(gpu).eval()
+    seeded_magnet_weights(model, seed=6)
+    inp = to_dev(synth.make_inputs(wl, B=B, seed=321, round_bf16=True), gpu)
+    x_d3 = (torch.randn(B, 256, wl.h, wl.w, generator=torch.Generator().manual_seed(4)) * 0.5).to(gpu)
+    with torch.no_grad():
+        full = model.match_and_refine(inp["ref_gmms"], x_d3, inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"],
+                                      inp["is_valid"], inp["cam_intrins"], mode="test")[-1].clone()
+    V = wl.V
+    for b in (0, 63):
+        sel = lambda t: t[b:b + 1].contiguous()
+        nb = inp["nghbr_feat"].view(V, B, *inp["nghbr_feat"].shape[1:])[:, b:b + 1].reshape(V, *inp["nghbr_feat"].shape[1:]).contiguous()
+        ng = inp["nghbr_gmms"].view(V, B, *inp["nghbr_gmms"].shape[1:])[:, b:b + 1].reshape(V, *inp["nghbr_gmms"].shape[1:]).contiguous()
+        with torch.no_grad():
+            one = model.match_and_refine(sel(inp["ref_gmms"]), sel(x_d3), sel(inp["ref_feat"]), nb, ng, sel(inp["nghbr_poses"]),
+                                         sel(inp["is_valid"]), {kk: sel(v) for kk, v in inp["cam_intrins"].items()}, mode="test")[-1]
+        assert torch.isfinite(one).all() and torch.equal(one[0], full[b]), f"frame {b}"
