@@ -193,3 +193,14 @@ def test_fnet_mfma_shapes_vs_torch(hip_lib, gpu, hw):
     err = ((out - ref).abs().max() / ref.abs().max()).item()
     print(f"F-Net {H}x{W}: max err / max|feat| = {err:.2e}")
     assert err < 2e-4
+
+
+def test_fnet_batch_invariance_at_bench_size(hip_lib, gpu):
+    """40 images of 480x640 in one pass (the F-Net benchmark batch) give, image by image, exactly what a one-image pass gives."""
+    m = seeded_fnet_state(fnet.PSMNet(feature_dim=64), seed=11).eval().to(gpu)
+    run = fnet.FNetMFMA(m)
+    imgs = torch.randn(40, 3, 480, 640, generator=torch.Generator().manual_seed(12)).to(gpu)
+    full = run.run(imgs).clone()
+    for i in (0, 39):
+        one = run.run(imgs[i:i + 1].contiguous())
+        assert torch.isfinite(one).all() and torch.equal(one[0], full[i]), f"image {i}"
