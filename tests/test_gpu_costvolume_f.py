@@ -137,3 +137,31 @@ def test_backward_kernels_agree(hip_lib, gpu):
         gr = gr.permute(0, 3, 1, 2).cpu().numpy(); gs = gs[:, 1:-1, 1:-1].permute(0, 3, 1, 2).cpu().numpy()
         for got, exp in ((gr, o_gr), (gs, o_gs)):
             np.testing.assert_allclose(got, exp, rtol=1e-4, atol=2e-5 * max(1.0, float(np.abs(exp).max())))
+
+
+def test_backward_full_training_shape_properties(hip_lib, gpu):
+    """The reference's F-Net training shape (120x160, V = 4, D = 80 SID bins, F = 64): too large for the oracle in a test, so
+    size-independent properties: the backward is linear in the upstream gradient, a zero gradient gives zeros, and
+    <grad_cost, cost(ref + e*dref) - cost(ref)> / e matches <grad_ref, dref> (the backward is the adjoint of the forward)."""
+    from magnet_amd import lib
+    wl = synth.Workload("f", "scannet", 120, 160, V=4, D=80, F=64)
+    B = 2
+    inp = synth.make_inputs(wl, B=B, seed=31, smooth_feats=True)
+    bnd = np.exp(np.log(10.0 + 1 - 1e-3) * np.arange(81) / 80) - (1 - 1e-3)
+    bins = [float(v) for v in ((bnd[:-1] + bnd[1:]) / 2).astype(np.float32)]
+    ref_cl = lib.pack_features(inp["ref_feat"].to(gpu), lib.FEAT_F32, pad=0); src_pad = lib.pack_features(inp["nghbr_feat"].to(gpu), lib.FEAT_F32, pad=1)
+    geo = (inp["nghbr_poses"].to(gpu), inp["is_valid"].int().to(gpu), inp["cam_intrins"]["intM"].to(gpu), inp["cam_intrins"]["unit_ray_array_2D"].to(gpu))
+    g = torch.Generator().manual_seed(32)
+    g1 = torch.randn(B, 80, 120, 160, generator=g).to(gpu); g2 = torch.randn(B, 80, 120, 160, generator=g).to(gpu)
+    bw = lambda gg: lib.cost_volume_f_backward(ref_cl, src_pad, *geo, bins, gg)
+    r1, s1 = bw(g1); r2, s2 = bw(g2); r12, s12 = bw(g1 + 2.0 * g2)
+    for a, b_ in ((r12, r1 + 2.0 * r2), (s12, s1 + 2.0 * s2)):
+        assert torch.allclose(a, b_, rtol=1e-3, atol=2e-4 * float(b_.abs().max()))
+    r0, s0 = bw(torch.zeros_like(g1))
+    assert not r0.any() and not s0.any()
+    # adjoint test on the reference features (the forward is linear in them)
+    fwd = lambda rc: lib.cost_volume_cw(rc, src_pad, None, *geo, 0.0, k_list=bins, mode=1)
+    dref = torch.randn(ref_cl.shape, generator=torch.Generator().manual_seed(33)).to(gpu)
+    lhs = ((fwd(ref_cl + dref) - fwd(ref_cl)).double() * g1.double()).sum().item()
+    rhs = (r1.double() * dref.double()).sum().item()
+    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
