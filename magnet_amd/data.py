@@ -92,39 +92,83 @@ class ScanNetFolder:
     def _scene(self, name):
         return os.path.join(self.root, name)
 
+    # file naming of the format; SevenScenesFolder overrides these
+    def _color(self, sdir, k):
+        return os.path.join(sdir, "color", f"{k}.jpg")
+
+    def _depth(self, sdir, k):
+        return os.path.join(sdir, "depth", f"{k}.png")
+
+    def _pose(self, sdir, k):
+        return os.path.join(sdir, "pose", f"{k}.txt")
+
+    def _intrinsics(self, scene, sdir, idx):
+        raw_w, raw_h = self._raw_wh(scene, idx)
+        return cam_intrinsics(read_matrix_txt(os.path.join(sdir, "intrinsic", "intrinsic_color.txt")), raw_w, raw_h, self.dpv_h, self.dpv_w)
+
+    def _split(self, sample):
+        scene, idx = sample
+        return scene, self._scene(scene), int(idx)
+
+    def _depth_metres(self, raw):
+        return raw.astype(np.float32) / 1000.0                                  # uint16 millimetres
+
     def _raw_wh(self, scene, any_idx):
         if scene not in self.raw_wh:
             from PIL import Image
-            with Image.open(os.path.join(self._scene(scene), "color", f"{any_idx}.jpg")) as im:
+            with Image.open(self._color(self._scene(scene), any_idx)) as im:
                 self.raw_wh[scene] = im.size                                   # (W, H)
         return self.raw_wh[scene]
 
     def __getitem__(self, i):
         from PIL import Image
-        scene, idx = self.samples[i]
-        idx = int(idx)
-        sdir = self._scene(scene)
-        frames = window_indices(idx, self.n_views, self.window_radius,
-                                lambda k: os.path.exists(os.path.join(sdir, "color", f"{k}.jpg")))
-        raw_w, raw_h = self._raw_wh(scene, idx)
-        intr = cam_intrinsics(read_matrix_txt(os.path.join(sdir, "intrinsic", "intrinsic_color.txt")), raw_w, raw_h,
-                              self.dpv_h, self.dpv_w)
+        scene, sdir, idx = self._split(self.samples[i])
+        frames = window_indices(idx, self.n_views, self.window_radius, lambda k: os.path.exists(self._color(sdir, k)))
+        intr = self._intrinsics(scene, sdir, idx)
         mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1); std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
         data_array = []
         for j, k in enumerate(frames):
-            with Image.open(os.path.join(sdir, "color", f"{k}.jpg")) as im:
+            with Image.open(self._color(sdir, k)) as im:
                 rgb = im.convert("RGB").resize((self.img_w, self.img_h), resample=Image.BILINEAR)
             img = torch.from_numpy(np.asarray(rgb).astype(np.float32) / 255.0).permute(2, 0, 1)
             img = (img - mean) / std
             if j == self.center:
-                with Image.open(os.path.join(sdir, "depth", f"{k}.png")) as dm:
-                    d = np.asarray(dm.resize((self.img_w, self.img_h), resample=Image.NEAREST)).astype(np.float32) / 1000.0
+                with Image.open(self._depth(sdir, k)) as dm:
+                    d = self._depth_metres(np.asarray(dm.resize((self.img_w, self.img_h), resample=Image.NEAREST)))
                 gt = torch.from_numpy(d)[None]
             else:
                 gt = 0.0
-            data_array.append({"img": img, "gt_dmap": gt, "extM": read_pose_txt(os.path.join(sdir, "pose", f"{k}.txt")),
+            data_array.append({"img": img, "gt_dmap": gt, "extM": read_pose_txt(self._pose(sdir, k)),
                                "scene_name": scene, "img_idx": str(k)})
         return data_array, intr
+
+
+class SevenScenesFolder(ScanNetFolder):
+    """7-Scenes layout (data/dataloader_7scenes.py): <root>/<scene>/seq-XX/frame-XXXXXX.{color.png,depth.png,pose.txt}; samples are
+    (scene, sequence id, frame index); the published intrinsics fx = fy = 585, c = (320, 240) apply to the 640x480 frames and are
+    scaled by the INPUT size, as the reference does (:78-100)."""
+
+    def _split(self, sample):
+        scene, seq, idx = sample
+        return "%s_seq-%02d" % (scene, int(seq)), os.path.join(self.root, scene, "seq-%02d" % int(seq)), int(idx)
+
+    def _depth_metres(self, raw):
+        raw = raw.copy()
+        raw[raw == 65535] = 0                                                    # the sensor's "no measurement" code (:150)
+        return raw.astype(np.float32) / 1000.0
+
+    def _color(self, sdir, k):
+        return os.path.join(sdir, "frame-%06d.color.png" % k)
+
+    def _depth(self, sdir, k):
+        return os.path.join(sdir, "frame-%06d.depth.png" % k)
+
+    def _pose(self, sdir, k):
+        return os.path.join(sdir, "frame-%06d.pose.txt" % k)
+
+    def _intrinsics(self, scene, sdir, idx):
+        K = np.eye(3); K[0, 0] = K[1, 1] = 585.0; K[0, 2], K[1, 2] = 320.0, 240.0
+        return cam_intrinsics(K, self.img_w, self.img_h, self.dpv_h, self.dpv_w)
 
 
 def collate(items):

@@ -75,3 +75,24 @@ def test_folder_loader_end_to_end(tmp_path):
     rel = poses_rel = np.linalg.inv(poses[8]) @ poses[6]                                           # ext_nghbr @ inv(ext_ref)
     np.testing.assert_allclose(nghbr_poses[0, 2].numpy(), rel, atol=1e-6)
     assert ref_dat["gt_dmap"].shape == (2, 1, 32, 48) and not nghbr_poses[0, 1].any()
+
+
+def test_seven_scenes_layout(tmp_path):
+    pytest.importorskip("PIL")
+    from PIL import Image
+    sdir = tmp_path / "chess" / "seq-03"
+    sdir.mkdir(parents=True)
+    rng = np.random.RandomState(1)
+    for i in range(0, 40, 5):
+        Image.fromarray(rng.randint(0, 255, (48, 64, 3), dtype=np.uint8)).save(sdir / ("frame-%06d.color.png" % i))
+        Image.fromarray((rng.rand(48, 64) * 3000 + 400).astype(np.uint16)).save(sdir / ("frame-%06d.depth.png" % i))
+        T = np.eye(4); T[:3, 3] = [0.02 * i, 0.0, 0.01 * i]
+        np.savetxt(sdir / ("frame-%06d.pose.txt" % i), T)
+    ds = data.SevenScenesFolder(str(tmp_path), [("chess", 3, 20)], n_views=2, window_radius=10, input_hw=(48, 64), dpv_hw=(12, 16))
+    arr, intr = ds[0]
+    assert [d["img_idx"] for d in arr] == ["10", "20", "30"] and arr[1]["gt_dmap"].shape == (1, 48, 64)
+    np.testing.assert_allclose(intr["intM"].numpy(), [[585 * 16 / 64, 0, 320 * 16 / 64], [0, 585 * 12 / 48, 240 * 12 / 48], [0, 0, 1]], rtol=1e-6)
+    np.testing.assert_allclose(arr[2]["extM"][:3, 3], [-0.6, 0.0, -0.3], atol=1e-12)                # inverse of the cam->world file
+    data_array, cam = next(data.batches(ds, 1))
+    _, _, poses, valid = data_preprocess(data_array, 1)
+    assert valid.tolist() == [[1, 1]] and poses.shape == (1, 2, 4, 4)
