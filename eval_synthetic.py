@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--dataset_path", default="", help="root of ScanNet-format scene folders (magnet_amd/data.py) instead of synthetic frames")
     ap.add_argument("--split", default="", help="text file of '<scene> <frame index>' lines (data_split/scannet_*.txt format)")
     ap.add_argument("--window_radius", type=int, default=20)
+    ap.add_argument("--dataset_format", default="scannet", choices=["scannet", "7scenes"],
+                    help="folder layout; the split file has '<scene> <frame>' or '<scene> <sequence> <frame>' lines")
     ap.add_argument("--psmnet", action="store_true", help="use the PSMNet F-Net (matrix-core path) instead of the stub F-Net")
     a = ap.parse_args()
     from tests.stubs import StubDNet, StubFNet, make_args, seeded_magnet_weights
@@ -96,8 +98,9 @@ def main():
     if a.dataset_path:
         from magnet_amd import data
         with open(a.split) as f:
-            samples = [ln.split()[:2] for ln in f if ln.strip()]
-        ds = data.ScanNetFolder(a.dataset_path, samples, n_views=a.V, window_radius=a.window_radius,
+            samples = [ln.split()[:3 if a.dataset_format == "7scenes" else 2] for ln in f if ln.strip()]
+        Folder = data.SevenScenesFolder if a.dataset_format == "7scenes" else data.ScanNetFolder
+        ds = Folder(a.dataset_path, samples, n_views=a.V, window_radius=a.window_radius,
                                 input_hw=(a.input_height, a.input_width), dpv_hw=(a.input_height // 4, a.input_width // 4))
         loader = data.batches(ds, a.batch)
         title = "scannet-format folder %s (%d windows) V=%d D=%d iters=%d" % (a.dataset_path, len(ds), a.V, a.D, a.iters)
