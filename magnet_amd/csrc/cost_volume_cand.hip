@@ -125,7 +125,6 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
     unsigned long long vmask = 0ull;
     for (int v = 0; v < p.V; ++v) vmask |= (unsigned long long)(p.is_valid[b * p.V + v] == 1) << v;
     vmask = __builtin_amdgcn_readfirstlane((uint32_t)vmask) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(vmask >> 32)) << 32);
-    CGmmPair g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};              // tap registers (only leader lanes' values are ever read)
     // (mu, sigma) of the wave's 16 reference pixels, lane q holds pixel q: read once per wave instead of a dependent global
     // load at the head of every pixel's view loop
     float mu_row = 0.f, sg_row = 0.f;
@@ -198,6 +197,9 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)KEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);  // wave_shr:1
                 if (j0 == 0) tprev = KEY_CLOSED;                                  // first candidate of a pixel group
                 const bool lead = inwin && (tkey != tprev);
+                // tap registers: only leader lanes' values are ever read (through ds_bpermute); declared per iteration so that
+                // they are not carried around the loop (8 VGPRs less during the correlation)
+                CGmmPair g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
                 if (lead && !(abl & 2) && !MODEF) {
                     g0 = *reinterpret_cast<const CGmmPair*>(sgm + qi * 8u);
                     g1 = *reinterpret_cast<const CGmmPair*>(sgm + (qi + (uint32_t)Wp) * 8u);
