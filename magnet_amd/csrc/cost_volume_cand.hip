@@ -51,6 +51,12 @@ __device__ __forceinline__ float creduce8(float v) {    // sum over aligned grou
     return v;
 }
 
+__device__ __forceinline__ float creduce4(float v) {    // sum over aligned groups of 4 lanes
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave execute in order; only the compiler must not reorder across this.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -66,8 +72,10 @@ constexpr uint32_t KEY_CLOSED = 0xffffffffu;
 // CPL  = 16-byte channel chunks per lane in the correlation (F*sizeof(FeatT)/16 <= 8*CPL), FULL = exactly
 // MINW = waves per SIMD to compile for; VAR = compile-time specialisation: 0 generic matcher (run-time options), 1 est_costvolume_F
 // mode, 2 production matcher (candidates sampled in-kernel, no stats counters, no dev ablations): fewer scalar tests and live registers
-template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int VAR>
+template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int VAR, int LPU = 8>
 __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
+    constexpr int IPP = 64 / (4 * LPU);                   // items per correlation pass: LPU lanes per (item, tap) unit
+    constexpr int CSTR = LPU * 16;                        // byte stride between a lane's channel chunks
     constexpr bool MODEF = VAR == 1;                      // est_costvolume_F semantics
     constexpr bool FASTV = VAR == 2;                      // production matcher: sampled candidates, no stats, no dev ablations
     const int abl = FASTV ? 0 : p.ablate;
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
     const int nchunk = (int)(texel_bytes / 16);
     // lane roles
     const int g = lane / DL, j0 = lane % DL;                                      // geometry: pixel group, candidate
-    const int sub = lane & 7, tap = (lane >> 3) & 3, upair = lane >> 5;           // correlation: chunk, tap, item 0/1
+    const int sub = lane & (LPU - 1), tap = (lane / LPU) & 3, upair = lane / (4 * LPU);   // correlation: chunk, tap, item of the pass
     const uint32_t lane_src_off = (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes + (uint32_t)sub * 16u;
     const unsigned char* __restrict__ ref_row = reinterpret_cast<const unsigned char*>(p.ref_feat) +
         ((size_t)b * hw + (size_t)yc * p.w) * texel_bytes;                        // reference features of this pixel row
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 const unsigned char* rp = ref_row + (__umul24((uint32_t)min(x, p.w - 1), texel_bytes) + (uint32_t)sub * 16u);
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc)
-                    rvp[cc] = (FULL || (sub + 8 * cc < nchunk)) ? *reinterpret_cast<const uint4*>(rp + cc * 128)
+                    rvp[cc] = (FULL || (sub + LPU * cc < nchunk)) ? *reinterpret_cast<const uint4*>(rp + cc * CSTR)
                                                                 : make_uint4(0, 0, 0, 0);
             }
             float d;
@@ -251,26 +259,26 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 wave_lds_fence();
 
                 // ---------------- correlation: unit = (item, tap), 8 lanes x 16 B per unit ----------------
-                const int passes = (abl & 1) ? 0 : (nitems + 1) >> 1;        // 2 items (8 units) per pass
+                const int passes = (abl & 1) ? 0 : (nitems + IPP - 1) / IPP;  // IPP items (4*IPP units) per pass
                 for (int ps = 0; ps < passes; ps += 2) {
                     uint4 sv[2][CPL], rv[2][CPL];
                     // second pass of the pair only if it holds an item (wave-uniform): at ~3.5 items per (pixel, view) a third of
                     // the iterations need one pass
-                    const bool second = (2 * (ps + 1) < nitems) || (abl & 32);
+                    const bool second = (IPP * (ps + 1) < nitems) || (abl & 32);
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
                         if (a == 1 && !second) break;
-                        const int it = min(2 * (ps + a) + upair, nitems);         // tail of an odd pass pair: the pad item
+                        const int it = min(IPP * (ps + a) + upair, nitems);       // tail of the last pass: the pad item
                         const uint32_t item = items[it];
                         const unsigned char* sp = src + (__umul24(item & 0xffffffu, texel_bytes) + lane_src_off);
                         const int xr = min(x_base + (int)(item >> 26), p.w - 1);
                         const unsigned char* rp = ref_row + (__umul24((uint32_t)xr, texel_bytes) + (uint32_t)sub * 16u);
 #pragma unroll
                         for (int cc = 0; cc < CPL; ++cc) {
-                            const bool okc = FULL || (sub + 8 * cc < nchunk);
-                            sv[a][cc] = okc ? *reinterpret_cast<const uint4*>(sp + cc * 128) : make_uint4(0, 0, 0, 0);
+                            const bool okc = FULL || (sub + LPU * cc < nchunk);
+                            sv[a][cc] = okc ? *reinterpret_cast<const uint4*>(sp + cc * CSTR) : make_uint4(0, 0, 0, 0);
                             if (PPW == 1) rv[a][cc] = rvp[cc];
-                            else rv[a][cc] = okc ? *reinterpret_cast<const uint4*>(rp + cc * 128) : make_uint4(0, 0, 0, 0);
+                            else rv[a][cc] = okc ? *reinterpret_cast<const uint4*>(rp + cc * CSTR) : make_uint4(0, 0, 0, 0);
                         }
                     }
 #pragma unroll
@@ -279,8 +287,8 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                         float part = 0.f;
 #pragma unroll
                         for (int cc = 0; cc < CPL; ++cc) part = cdot_chunk(rv[a][cc], sv[a][cc], part, FeatT());
-                        part = creduce8(part);
-                        const int it = 2 * (ps + a) + upair;
+                        part = LPU == 8 ? creduce8(part) : creduce4(part);
+                        const int it = IPP * (ps + a) + upair;
                         if (sub == 0 && it < nitems) ctab[it * 4 + tap] = part;
                     }
                 }
@@ -329,13 +337,13 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
 template <int DL>
 static size_t cand_lds_bytes(const CvParams& p) { return (size_t)4 * (p.V * 512 + 1024 + 272 + 8 * DL * 4); }
 
-template <typename FeatT, int DL, int CPL, bool FULL, int MINW>
+template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU = 8>
 static hipError_t launch_cand(const CvParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
-    if (p.mode_f) hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 1>), grid, block, cand_lds_bytes<DL>(p), stream, p);
+    if (p.mode_f) hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 1, LPU>), grid, block, cand_lds_bytes<DL>(p), stream, p);
     else if (!p.d_volume && !p.stats && !p.ablate)
-        hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 2>), grid, block, cand_lds_bytes<DL>(p), stream, p);
-    else hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 0>), grid, block, cand_lds_bytes<DL>(p), stream, p);
+        hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 2, LPU>), grid, block, cand_lds_bytes<DL>(p), stream, p);
+    else hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 0, LPU>), grid, block, cand_lds_bytes<DL>(p), stream, p);
     return hipGetLastError();
 }
 
@@ -358,6 +366,7 @@ hipError_t launch_cv_cand(const CvParams& p, hipStream_t stream, bool* handled) 
     const int nchunk = (int)(p.F * esz / 16);
     *handled = true;
     if (p.feat_bf16) {
+        if (nchunk == 8 && p.D > 32) return launch_cand<uint16_t, 64, 2, true, 6, 4>(p, stream);   // F = 64: 4 lanes x 32 B per unit
         if (nchunk == 8)  return launch_cand_c<uint16_t, 1, true>(p, stream);        // F = 64
         if (nchunk <= 8)  return launch_cand_c<uint16_t, 1, false>(p, stream);
         if (nchunk <= 16) return launch_cand_c<uint16_t, 2, false>(p, stream);
