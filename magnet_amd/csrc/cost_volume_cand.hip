@@ -347,14 +347,14 @@ static hipError_t launch_cand(const CvParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <typename FeatT, int CPL, bool FULL>
+template <typename FeatT, int CPL, bool FULL, int LPU = 8>
 static hipError_t launch_cand_c(const CvParams& p, hipStream_t stream) {
-    if (p.D <= 8)       return launch_cand<FeatT, 8, CPL, FULL, 4>(p, stream);
-    else if (p.D <= 16) return launch_cand<FeatT, 16, CPL, FULL, 4>(p, stream);
-    else if (p.D <= 32) return launch_cand<FeatT, 32, CPL, FULL, 4>(p, stream);
+    if (p.D <= 8)       return launch_cand<FeatT, 8, CPL, FULL, 4, LPU>(p, stream);
+    else if (p.D <= 16) return launch_cand<FeatT, 16, CPL, FULL, 4, LPU>(p, stream);
+    else if (p.D <= 32) return launch_cand<FeatT, 32, CPL, FULL, 4, LPU>(p, stream);
     // fp32 features carry twice the chunk registers: 6 waves/SIMD spills 76 B/lane there, 5 does not
-    if (sizeof(FeatT) == 4) return launch_cand<FeatT, 64, CPL, FULL, 5>(p, stream);
-    return launch_cand<FeatT, 64, CPL, FULL, 6>(p, stream);
+    if (sizeof(FeatT) == 4) return launch_cand<FeatT, 64, CPL, FULL, 5, LPU>(p, stream);
+    return launch_cand<FeatT, 64, CPL, FULL, 6, LPU>(p, stream);
 }
 
 hipError_t launch_cv_cand(const CvParams& p, hipStream_t stream, bool* handled) {
@@ -366,8 +366,7 @@ hipError_t launch_cv_cand(const CvParams& p, hipStream_t stream, bool* handled) 
     const int nchunk = (int)(p.F * esz / 16);
     *handled = true;
     if (p.feat_bf16) {
-        if (nchunk == 8 && p.D > 32) return launch_cand<uint16_t, 64, 2, true, 6, 4>(p, stream);   // F = 64: 4 lanes x 32 B per unit
-        if (nchunk == 8)  return launch_cand_c<uint16_t, 1, true>(p, stream);        // F = 64
+        if (nchunk == 8)  return launch_cand_c<uint16_t, 2, true, 4>(p, stream);     // F = 64: 4 lanes x 32 B per (item, tap) unit
         if (nchunk <= 8)  return launch_cand_c<uint16_t, 1, false>(p, stream);
         if (nchunk <= 16) return launch_cand_c<uint16_t, 2, false>(p, stream);
     } else {
