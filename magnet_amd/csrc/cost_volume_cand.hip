@@ -17,8 +17,8 @@
 //     an iteration (taps, then feature texels).
 // The bilinear interpolation is pulled out of the channel sum exactly as in the worklist kernel:
 //   sum_f ref[f]*bilerp(src[f]; taps) = bilerp(<ref, src[tap]>; taps): one F-channel dot product per
-// distinct (quad, tap), 8 lanes per dot product (16 B of channels each), v_dot2c_f32_bf16 / v_fma_f32,
-// 3-step DPP reduction.  Geometry and gates are the oracle's to the bit (warp_math.hpp); only the
+// distinct (quad, tap), LPU lanes per dot product (4 x 32 B for bf16 F = 64, else 8 x 16 B), v_dot2c_f32_bf16 / v_fma_f32,
+// DPP reduction.  Geometry and gates are the oracle's to the bit (warp_math.hpp); only the
 // association of the fp32 channel sum differs (tolerance in tests/parity.py).
 //
 // Workgroup = 256 threads = 4 independent waves; wave w owns row w of a 16x4 pixel tile.  There is
