@@ -38,7 +38,7 @@ extern "C" {
 
 #define MAGNET_API __attribute__((visibility("default")))
 
-#define MAGNET_HIP_VERSION 100            /* major*10000 + minor*100 + patch */
+#define MAGNET_HIP_VERSION 200            /* major*10000 + minor*100 + patch */
 
 enum {                                     /* storage dtype of channel-last feature maps */
     MAGNET_FEAT_F32  = 0,
@@ -76,9 +76,18 @@ typedef struct MagnetCostVolumeArgs {
     const float   *intM;                   /* (B,3,3) intrinsics at grid resolution */
     const float   *rays;                   /* (B,3,h*w) unit_ray_array_2D */
     float         *cost;                   /* OUT (B,D,h,w) fp32; frame b starts at cost + b*cost_batch_stride */
-    int32_t        path;                   /* kernel selection: 0 = auto (candidate-lane kernel; generic for shapes it
-                                              does not take); 1 = generic gather kernel (bit-exact reference path);
-                                              2 = candidate-lane kernel or error; 3 = pixel-lane worklist kernel */
+    int32_t        path;                   /* kernel selection, low 8 bits:
+                                              0 = auto: the PRODUCTION matcher (tolerance parity: gate-flip fraction <= 1e-5,
+                                                  values within 2e-5 + 2e-5|c| of the reference elsewhere) whenever the candidates
+                                                  are sampled in the kernel (d_volume == NULL, mode 0, stats == NULL); otherwise
+                                                  the exact candidate-lane kernel; the generic kernel for shapes neither takes;
+                                              1 = generic gather kernel (bit-exact reference arithmetic, slow);
+                                              2 = exact candidate-lane kernel (the reference's fp32 geometry to the bit) or error;
+                                              3 = exact pixel-lane worklist kernel or error;
+                                              4 = production matcher or error.
+                                              Bits 8..15 are DEVELOPMENT switches (timing ablations used by tools/ablate.py;
+                                              results are not meaningful with any of them set except bit 8 on path 0/4, which
+                                              only moves the channel contraction from the matrix pipe to the vector ALU). */
     uint32_t      *stats;                  /* optional device uint32[4]: {tiles run by a fast kernel, tiles run by the
                                               generic kernel, items (distinct open quads) correlated, 0}, accumulated with atomics; NULL = off */
     int64_t        cost_batch_stride;      /* elements between consecutive frames of `cost`; 0 = D*h*w (dense).
@@ -95,6 +104,10 @@ typedef struct MagnetCostVolumeArgs {
                                                   bins d_center (same for all pixels), there is no gate (src_gmm_pad,
                                                   ref_gmm unused, may be NULL) and views are summed in fp32 (:42).
                                                   Candidate-lane and generic kernels only. */
+    uint8_t       *gate_bits;              /* optional debug OUT (B,V,D,h,w) uint8: the consistency gate of every
+                                              (view, candidate, pixel) sample, homography.py:157-158 (1 = open).  Written by the
+                                              production matcher (path 0/4) and by the exact candidate-lane kernel (path 2);
+                                              entries of invalid views are not written (zero the buffer first).  NULL = off. */
 } MagnetCostVolumeArgs;
 
 MAGNET_API int magnet_version(void);

@@ -115,10 +115,13 @@ static int cv_prepare(const MagnetCostVolumeArgs* a, magnet::CvParams& p, bool b
     p.ref_gmm = a->ref_gmm; p.d_volume = a->d_volume; p.poses = a->poses; p.is_valid = a->is_valid;
     p.intM = a->intM; p.rays = a->rays; p.cost = a->cost; p.stats = a->stats;
     p.cost_hi = (uint16_t*)a->cost_hi; p.cost_lo = (uint16_t*)a->cost_lo; p.cost_ld = a->cost_ld;
+    p.gate_bits = a->gate_bits;
     if (a->cost_hi && (!a->cost_lo || a->cost_ld < a->D))
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: cost_hi needs cost_lo and cost_ld >= D");
-    if (a->cost_hi && (a->path & 0xff) != 0 && (a->path & 0xff) != 2)
-        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the split channel-last output exists only in the candidate-lane kernel (path 0/2)");
+    if (a->cost_hi && (a->path & 0xff) != 0 && (a->path & 0xff) != 2 && (a->path & 0xff) != 4)
+        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the split channel-last output exists only in the candidate-lane kernels (path 0/2/4)");
+    if (a->gate_bits && ((a->path & 0xff) == 1 || (a->path & 0xff) == 3 || a->mode != 0))
+        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: gate_bits is written by the candidate-lane kernels only (path 0/2/4, mode 0)");
     p.cost_bstride = a->cost_batch_stride ? a->cost_batch_stride : (long long)a->D * a->h * a->w;
     if (p.cost_bstride < (long long)a->D * a->h * a->w)
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: cost_batch_stride smaller than D*h*w");
@@ -133,21 +136,29 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
     hipError_t e = hipSuccess;
     bool handled = false;
     const int path = a->path & 0xff;
-    if (path == 0 || path == 2) {
+    if (path == 0 || path == 4) {
+        e = magnet::launch_cv_fast(p, (hipStream_t)stream, &handled);
+        if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw production-matcher launch");
+        if (!handled && path == 4)
+            return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the production matcher needs fused sampling (d_volume == NULL), mode 0, "
+                                      "stats == NULL and F*sizeof(feature) <= 512");
+    }
+    if (!handled && (path == 0 || path == 2)) {
         e = magnet::launch_cv_cand(p, (hipStream_t)stream, &handled);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw candidate-lane launch");
         if (!handled && path == 2)
             return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the candidate-lane kernel does not take this shape");
+    } else if (handled) {
     } else if (path == 3) {
         e = magnet::launch_cv_worklist(p, (hipStream_t)stream, &handled);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw worklist launch");
         if (!handled)
             return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the worklist kernel does not take this shape (D > 128 or very wide F)");
-    } else if (path != 1) {
+    } else if (path != 1 && path != 4) {
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: unknown path %d", path);
     }
     if (!handled) {
-        if (a->cost_hi) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: this shape falls back to the generic kernel, which has no split output");
+        if (a->cost_hi || a->gate_bits) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: this shape falls back to the generic kernel, which has no split / gate-bit output");
         e = magnet::launch_cv_generic(p, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw generic launch");
     }

@@ -240,6 +240,8 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
                 };
                 const bool spec = (abl & 16) && !(abl & 8);
                 if (!spec) eval_gate();
+                if (!FASTV && !MODEF && p.gate_bits && live)                      // debug output of the gate bits (parity tests)
+                    p.gate_bits[(((size_t)b * p.V + v) * p.D + j) * hw + (size_t)y * p.w + x] = gate ? 1 : 0;
                 const bool open = spec ? inwin : gate;                               // lanes whose quad becomes an item
 
                 // ---------------- distinct open quads of the wave -> items ----------------
@@ -341,7 +343,7 @@ template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU = 8>
 static hipError_t launch_cand(const CvParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
     if (p.mode_f) hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 1, LPU>), grid, block, cand_lds_bytes<DL>(p), stream, p);
-    else if (!p.d_volume && !p.stats && !p.ablate)
+    else if (!p.d_volume && !p.stats && !p.ablate && !p.gate_bits)
         hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 2, LPU>), grid, block, cand_lds_bytes<DL>(p), stream, p);
     else hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 0, LPU>), grid, block, cand_lds_bytes<DL>(p), stream, p);
     return hipGetLastError();

@@ -1,0 +1,373 @@
+// cost_volume_fast.hip — the PRODUCTION matcher: fused sampling + warp + gate + score with TOLERANCE parity.
+//
+// Same mapping as cost_volume_cand.hip (lane = depth candidate, a wave walks over 16 reference pixels of one
+// tile row, distinct gate-open quads of a (pixel, view) become ITEMS, one F-channel dot product per (item, tap)),
+// but the per-candidate arithmetic is no longer the reference's rounding sequence operation for operation.
+// north_star's contract is abs_rel < 1e-4 on the final depth and SURVEY.md §7 allows a ~1e-5 fraction of flipped
+// consistency gates; what this kernel computes instead of homography.py:131-148,157-159 / MAGNET.py:155:
+//   d      = fma(sigma, k_j, mu)                         (reference: mul, then add)
+//   P      = fma(r_pix, d, t_pix), z = fma(r_z, d, t_z)  (reference: mul, then add)
+//   1/P_z  = v_rcp_f32 (1 ulp)                           (reference: IEEE division by P_z + 1e-10; the 1e-10 only
+//            matters for |P_z| < ~1e-3, where the sample is far outside the image either way)
+//   texel position directly in PADDED-map coordinates: ixs = fma(P_x, 1/P_z, 0.5) (= u - 0.5 + 1), no
+//            normalise -> clamp(+-10) -> unnormalise round trip (homography.py:141-148 + ATen's unnormalise): every
+//            clamped coordinate is out of the image, and so is every coordinate this kernel rejects by its window test
+//   window test as one unsigned compare of the float's bit pattern per axis (0 <= ixs < w + 1)
+//   views summed in fp32 (reference: fp64, homography.py:116-118,159), division by V as a multiplication by 1/V
+// Modelled on the CPU against the oracle's gate bits (tools/flip_model.py): 4e-6 of the gates differ at C2; measured
+// on the device by tests/test_gpu_fast_matcher.py (gate bits through the `gate_bits` debug output, value tolerance
+// 2e-5 + 2e-5 |oracle| elsewhere, abs_rel of the refinement loop).
+//
+// Instruction diet relative to cost_volume_cand.hip (per (pixel, view) wave-iteration, bf16 F = 64, D = 64):
+//   * frame / view base addresses are wave-uniform (readfirstlane) -> scalar address arithmetic, 32-bit lane offsets
+//   * (mu,sigma) taps: every lane loads its own 2 x 16 B (no leader election, no ds_bpermute)
+//   * bf16 features with D >= 64: the (item, tap) x channel contraction runs on the MATRIX pipe:
+//     v_mfma_f32_16x16x32_bf16 with A = 16 (item, tap) units x 32 channels, B = the pixel's reference vector in all
+//     16 columns (1/16 of the tile is useful, but the matrix pipe is otherwise idle here and its result layout is exactly
+//     "lane group g = item g, register t = tap t"): no v_dot2c, no DPP reduction
+//   * no fp64, no exec-mask branches around the gate / combine
+// Everything that needs the reference's exact rounding (explicit d_volume, est_costvolume_F mode, stats) stays in
+// cost_volume_cand.hip / cost_volume.hip.
+#include "cv_common.hpp"
+
+namespace magnet {
+
+typedef __attribute__((ext_vector_type(2))) __bf16 fbf16x2_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 fbf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float ff32x4_t;
+
+__device__ __forceinline__ float fdot_chunk(const uint4 a, const uint4 b, float acc, uint16_t) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fbf16x2_t, a.x), __builtin_bit_cast(fbf16x2_t, b.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fbf16x2_t, a.y), __builtin_bit_cast(fbf16x2_t, b.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fbf16x2_t, a.z), __builtin_bit_cast(fbf16x2_t, b.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fbf16x2_t, a.w), __builtin_bit_cast(fbf16x2_t, b.w), acc, false);
+    return acc;
+}
+__device__ __forceinline__ float fdot_chunk(const uint4 a, const uint4 b, float acc, float) {
+    acc = __builtin_fmaf(__uint_as_float(a.x), __uint_as_float(b.x), acc);
+    acc = __builtin_fmaf(__uint_as_float(a.y), __uint_as_float(b.y), acc);
+    acc = __builtin_fmaf(__uint_as_float(a.z), __uint_as_float(b.z), acc);
+    acc = __builtin_fmaf(__uint_as_float(a.w), __uint_as_float(b.w), acc);
+    return acc;
+}
+
+__device__ __forceinline__ float freduce8(float v) {    // sum over aligned groups of 8 lanes
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ float freduce4(float v) {    // sum over aligned groups of 4 lanes
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+    return v;
+}
+
+__device__ __forceinline__ void fwave_lds_fence() {
+    // LDS operations of one wave execute in order; only the compiler must not reorder across this.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr uint32_t FKEY_CLOSED = 0xffffffffu;
+
+// DL   = candidates per pixel group inside a wave (8,16,32,64); PPW = 64/DL pixels per iteration
+// CPL  = 16-byte channel chunks per lane in the VALU correlation (F*sizeof(FeatT)/16 <= LPU*CPL), FULL = exactly
+// MINW = waves per SIMD to compile for; LPU = lanes per (item, tap) unit of the VALU correlation
+// OPT  = bit 0: correlation on the matrix pipe (bf16, DL = 64, F = 32*KS); bit 1: write gate bits (debug / parity tests)
+// KS   = K steps of 32 channels of the MFMA correlation
+template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU, int OPT, int KS>
+__global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
+    constexpr bool MFMA = (OPT & 1) != 0;
+    constexpr bool GBITS = (OPT & 2) != 0;
+    constexpr int IPP = MFMA ? 4 : 64 / (4 * LPU);        // items per correlation pass
+    constexpr int CSTR = LPU * 16;                        // byte stride between a lane's channel chunks (VALU correlation)
+    constexpr int PPW = 64 / DL;
+    static_assert(!MFMA || (PPW == 1 && sizeof(FeatT) == 2), "MFMA correlation: bf16 features, one pixel per wave iteration");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_v, b_v;
+    tile_of_block(p, tile_v, b_v);
+    const int tile = __builtin_amdgcn_readfirstlane(tile_v), b = __builtin_amdgcn_readfirstlane(b_v);   // wave-uniform
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int y = ty * TILE_H + wv;                       // this wave's pixel row
+    const int yc = min(y, p.h - 1);
+    const int x_base = tx * TILE_W;
+    const size_t hw = (size_t)p.h * p.w;
+    const int Wp = p.w + 2, Hp = p.h + 2;
+    const int JB = (p.D + DL - 1) / DL;                   // candidate blocks per pixel
+
+    // ---- wave-private LDS ----
+    constexpr int OUT_PX = 8;                             // pixels staged before a coalesced flush (32-byte row segments)
+    const int out_bytes = p.cost_hi ? 0 : OUT_PX * DL * 4;
+    const int wave_bytes = p.V * 512 + 16 + 1024 + 272 + out_bytes;
+    unsigned char* wbase = smem + wv * wave_bytes;
+    float4*   pvtab = reinterpret_cast<float4*>(wbase);                               // [V][16 px][2]
+    float4*   ctab  = reinterpret_cast<float4*>(wbase + p.V * 512);                   // [zero slot for closed lanes | 64 items] x 4 taps
+    uint32_t* items = reinterpret_cast<uint32_t*>(wbase + p.V * 512 + 16 + 1024);     // [64 + pad]
+    float*    outb  = reinterpret_cast<float*>(wbase + p.V * 512 + 16 + 1024 + 272);  // [OUT_PX][DL] results of one block
+
+    // ---- depth-linear projection terms for the wave's 16 pixels x V views (once per tile row) ----
+    for (int e = lane; e < 16 * p.V; e += 64) {
+        const int q = e & 15, v = e >> 4;
+        const int xc = min(x_base + q, p.w - 1);
+        const size_t pix = (size_t)yc * p.w + xc;
+        const float r0 = p.rays[((size_t)b * 3 + 0) * hw + pix];
+        const float r1 = p.rays[((size_t)b * 3 + 1) * hw + pix];
+        const float r2 = p.rays[((size_t)b * 3 + 2) * hw + pix];
+        const PixelView pv = make_pixel_view(p.intM + (size_t)b * 9, p.poses + ((size_t)b * p.V + v) * 16, r0, r1, r2);
+        pvtab[e * 2 + 0] = make_float4(pv.rpx, pv.rpy, pv.rpz, pv.rcz);
+        pvtab[e * 2 + 1] = make_float4(pv.kt0, pv.kt1, pv.kt2, pv.tz);
+    }
+    if (lane == 0) ctab[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    fwave_lds_fence();
+
+    const uint32_t texel_bytes = (uint32_t)p.F * (uint32_t)sizeof(FeatT);
+    const int nchunk = (int)(texel_bytes / 16);
+    // window 0 <= ixs < w + 1 (padded-map coordinates) as an unsigned compare of the float bits: negative values have the
+    // sign bit set, NaNs are above every finite pattern
+    const uint32_t xlim = __float_as_uint((float)(p.w + 1)), ylim = __float_as_uint((float)(p.h + 1));
+    // lane roles
+    const int g = lane / DL, j0 = lane % DL;                                      // geometry: pixel group, candidate
+    // correlation, VALU form: chunk, tap, item of the pass.  MFMA form: A row = lane & 15 = (item of the pass, tap), K slot = lane >> 4
+    const int sub = MFMA ? (lane >> 4) : (lane & (LPU - 1));
+    const int tap = MFMA ? (lane & 3) : ((lane / LPU) & 3);
+    const int upair = MFMA ? ((lane & 15) >> 2) : (lane / (4 * LPU));
+    const uint32_t lane_src_off = (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes + (uint32_t)sub * 16u;
+    const unsigned char* __restrict__ ref_row = reinterpret_cast<const unsigned char*>(p.ref_feat) +
+        ((size_t)b * hw + (size_t)yc * p.w) * texel_bytes;                        // reference features of this pixel row
+    const float invV = 1.0f / (float)p.V;
+    // view validity (homography.py:97) as a bitmask read ONCE
+    unsigned long long vmask = 0ull;
+    for (int v = 0; v < p.V; ++v) vmask |= (unsigned long long)(p.is_valid[b * p.V + v] == 1) << v;
+    vmask = __builtin_amdgcn_readfirstlane((uint32_t)vmask) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(vmask >> 32)) << 32);
+    // (mu, sigma) of the wave's 16 reference pixels, lane q holds pixel q
+    float mu_row, sg_row;
+    {
+        const size_t pixr = (size_t)yc * p.w + min(x_base + (lane & 15), p.w - 1);
+        mu_row = p.ref_gmm[((size_t)b * 2 + 0) * hw + pixr];
+        sg_row = p.ref_gmm[((size_t)b * 2 + 1) * hw + pixr];
+    }
+    const size_t map_texels = (size_t)Hp * Wp;
+    // source view v of frame b is image v*B + b (view-major, homography.py:105): walk the views by a constant stride
+    const size_t src_vstride = (size_t)p.B * map_texels * texel_bytes, sgm_vstride = (size_t)p.B * map_texels * 8;
+    const unsigned char* const src_b = reinterpret_cast<const unsigned char*>(p.src_feat) + (size_t)b * map_texels * texel_bytes;
+    const unsigned char* const sgm_b = reinterpret_cast<const unsigned char*>(p.src_gmm) + (size_t)b * map_texels * 8;
+    const float kappa = p.kappa;
+
+    for (int jb = 0; jb < JB; ++jb) {                                             // candidate block of DL candidates
+        const int j = jb * DL + j0;
+        const float kj = p.k[min(j, p.D - 1)];
+        for (int qb = 0; qb < 16 / PPW; ++qb) {
+            const int q = qb * PPW + g;                                           // pixel within the wave's row
+            const int x = x_base + q;
+            const bool live = (x < p.w) && (y < p.h) && (j < p.D);
+            // PPW == 1: every correlation unit of this iteration belongs to this one pixel: its reference vector stays in
+            // registers for all views (VALU form: the lane's chunk(s); MFMA form: the B fragments, same vector in all 16 columns)
+            uint4 rvp[MFMA ? KS : CPL];
+            if (PPW == 1) {
+                const unsigned char* rp = ref_row + (__umul24((uint32_t)min(x, p.w - 1), texel_bytes) + (uint32_t)sub * 16u);
+#pragma unroll
+                for (int cc = 0; cc < (MFMA ? KS : CPL); ++cc)
+                    rvp[cc] = (MFMA || FULL || (sub + LPU * cc < nchunk)) ? *reinterpret_cast<const uint4*>(rp + cc * (MFMA ? 64 : CSTR))
+                                                                          : make_uint4(0, 0, 0, 0);
+            }
+            float d;
+            {
+                const float mu = PPW == 1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu_row), qb)) : __shfl(mu_row, q);
+                const float sg = PPW == 1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg_row), qb)) : __shfl(sg_row, q);
+                d = __builtin_fmaf(sg, kj, mu);                                   // MAGNET.py:155
+            }
+            d = live ? d : __builtin_nanf("");                                    // dead lane -> out of image below
+            float acc = 0.f;
+
+            const unsigned char* __restrict__ src = src_b;
+            const unsigned char* __restrict__ sgm = sgm_b;
+            for (int v = 0; v < p.V; ++v, src += src_vstride, sgm += sgm_vstride) {
+                if (!((vmask >> v) & 1ull)) continue;                            // homography.py:97 (wave-uniform)
+                // ---------------- geometry ----------------
+                const float4 pa = pvtab[(v * 16 + q) * 2 + 0], pb = pvtab[(v * 16 + q) * 2 + 1];
+                const float Px = __builtin_fmaf(pa.x, d, pb.x);                  // homography.py:132
+                const float Py = __builtin_fmaf(pa.y, d, pb.y);
+                const float Pz = __builtin_fmaf(pa.z, d, pb.z);
+                const float zw = __builtin_fmaf(pa.w, d, pb.w);                  // homography.py:137-138
+                const float rz = __builtin_amdgcn_rcpf(Pz);                      // homography.py:133
+                const float ixs = __builtin_fmaf(Px, rz, 0.5f);                  // = (u - 0.5) + 1: padded-map texel coordinate
+                const float iys = __builtin_fmaf(Py, rz, 0.5f);
+                const float x0f = __builtin_floorf(ixs), y0f = __builtin_floorf(iys);
+                const float bx = ixs - x0f, by = iys - y0f;
+                const float ax = 1.0f - bx, ay = 1.0f - by;
+                const float wnw = ax * ay, wne = bx * ay, wsw = ax * by, wse = bx * by;   // homography.py:150-152
+                const bool inwin = (__float_as_uint(ixs) < xlim) && (__float_as_uint(iys) < ylim);
+                const uint32_t qi = inwin ? (uint32_t)__mul24((int)y0f, Wp) + (uint32_t)(int)x0f : 0u;   // quad origin, padded map
+                // ---------------- (mu,sigma) taps + consistency gate ----------------
+                const float4 g0 = *reinterpret_cast<const float4*>(sgm + qi * 8u);                 // (mu,sg) x0, x0+1 of row y0
+                const float4 g1 = *reinterpret_cast<const float4*>(sgm + (qi + (uint32_t)Wp) * 8u);
+                float mu_w = g0.x * wnw, sg_w = g0.y * wnw;
+                mu_w = __builtin_fmaf(g0.z, wne, mu_w); sg_w = __builtin_fmaf(g0.w, wne, sg_w);
+                mu_w = __builtin_fmaf(g1.x, wsw, mu_w); sg_w = __builtin_fmaf(g1.y, wsw, sg_w);
+                mu_w = __builtin_fmaf(g1.z, wse, mu_w); sg_w = __builtin_fmaf(g1.w, wse, sg_w);
+                const bool gate = inwin && (__builtin_fabsf(zw - mu_w) < sg_w * kappa);          // homography.py:157-158
+                if (GBITS && live)
+                    p.gate_bits[(((size_t)b * p.V + v) * p.D + j) * hw + (size_t)y * p.w + x] = gate ? 1 : 0;
+
+                // ---------------- distinct open quads of the wave -> items ----------------
+                const uint32_t key = gate ? qi : FKEY_CLOSED;
+                uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)key, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                if (PPW > 1 && j0 == 0) prev = FKEY_CLOSED;                       // first candidate of a pixel group
+                const bool fresh = gate && (key != prev);
+                const unsigned long long bal = __ballot(fresh);
+                if (bal == 0ull) continue;                                        // wave-uniform: nothing open in this view
+                const int nitems = __popcll(bal);
+                const int incl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                      __builtin_amdgcn_mbcnt_lo((uint32_t)bal, fresh ? 1u : 0u));   // items at or below this lane
+                if (fresh) items[incl - 1] = PPW == 1 ? qi : (((uint32_t)q << 26) | qi);
+                if (lane == 0) items[nitems] = 0u;                                // pad to a whole pass: pixel 0, texel 0
+                fwave_lds_fence();
+
+                // ---------------- correlation ----------------
+                if (MFMA) {
+                    // rows of A = (item of the pass, tap); B = the pixel's reference vector in every column: lane group g4 = lane >> 4
+                    // ends up with C[reg t] = <ref, src[item g4, tap t]>
+                    for (int ps = 0; ps < nitems; ps += 4) {
+                        const uint32_t item = items[min(ps + upair, nitems)];
+                        const unsigned char* sp = src + (__umul24(item, texel_bytes) + lane_src_off);
+                        uint4 av[KS];
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) av[ks] = *reinterpret_cast<const uint4*>(sp + ks * 64);
+                        ff32x4_t c4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+                            c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(fbf16x8_t, av[ks]),
+                                                                         __builtin_bit_cast(fbf16x8_t, rvp[ks]), c4, 0, 0, 0);
+                        const int it = ps + (lane >> 4);
+                        if ((lane & 15) == 0 && it < nitems)
+                            ctab[it + 1] = make_float4(c4[0], c4[1], c4[2], c4[3]);
+                    }
+                } else {
+                    const int passes = (nitems + IPP - 1) / IPP;
+                    for (int ps = 0; ps < passes; ps += 2) {
+                        uint4 sv[2][CPL], rv[2][CPL];
+                        const bool second = IPP * (ps + 1) < nitems;             // second pass of the pair only if it holds an item
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            if (a == 1 && !second) break;
+                            const int it = min(IPP * (ps + a) + upair, nitems);   // tail of the last pass: the pad item
+                            const uint32_t item = items[it];
+                            const unsigned char* sp = src + (__umul24(item & 0xffffffu, texel_bytes) + lane_src_off);
+                            const int xr = min(x_base + (int)(item >> 26), p.w - 1);
+                            const unsigned char* rp = ref_row + (__umul24((uint32_t)xr, texel_bytes) + (uint32_t)sub * 16u);
+#pragma unroll
+                            for (int cc = 0; cc < CPL; ++cc) {
+                                const bool okc = FULL || (sub + LPU * cc < nchunk);
+                                sv[a][cc] = okc ? *reinterpret_cast<const uint4*>(sp + cc * CSTR) : make_uint4(0, 0, 0, 0);
+                                if (PPW == 1) rv[a][cc] = rvp[cc];
+                                else rv[a][cc] = okc ? *reinterpret_cast<const uint4*>(rp + cc * CSTR) : make_uint4(0, 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            if (a == 1 && !second) break;
+                            float part = 0.f;
+#pragma unroll
+                            for (int cc = 0; cc < CPL; ++cc) part = fdot_chunk(rv[a][cc], sv[a][cc], part, FeatT());
+                            part = LPU == 8 ? freduce8(part) : freduce4(part);
+                            const int it = IPP * (ps + a) + upair;
+                            if (sub == 0 && it < nitems) reinterpret_cast<float*>(ctab + it + 1)[tap] = part;
+                        }
+                    }
+                }
+                fwave_lds_fence();
+
+                // ---------------- bilinear combine + view accumulation ----------------
+                {
+                    const float4 c4 = ctab[gate ? incl : 0];                      // closed lanes: the zero slot
+                    float c = c4.x * wnw;
+                    c = __builtin_fmaf(c4.y, wne, c);
+                    c = __builtin_fmaf(c4.z, wsw, c);
+                    c = __builtin_fmaf(c4.w, wse, c);
+                    acc += c;                                                     // homography.py:159,116 (fp32 here)
+                }
+                fwave_lds_fence();                                                // ctab/items are rewritten by the next view
+            }
+            const float cval = acc * invV;                                        // homography.py:118,120
+            if (p.cost_hi) {
+                // split-bf16 channel-last output for the conv kernel: lanes = consecutive channels of one row
+                if (live) {
+                    const uint16_t hi = f32_to_bf16_rne(cval);
+                    const uint16_t lo = f32_to_bf16_rne(cval - bf16_to_f32(hi));
+                    const size_t e = (((size_t)b * Hp + (y + 1)) * Wp + (x + 1)) * (size_t)p.cost_ld + j;
+                    p.cost_hi[e] = hi; p.cost_lo[e] = lo;
+                }
+                continue;
+            }
+            outb[(q & (OUT_PX - 1)) * DL + j0] = cval;
+            if ((((qb + 1) * PPW) & (OUT_PX - 1)) == 0) {
+                // ---- OUT_PX px x DL results: LDS -> coalesced row segments of cost[b, j, y, :] ----
+                const int q_base = (qb + 1) * PPW - OUT_PX;
+                fwave_lds_fence();
+                if (y < p.h) {
+                    for (int e = lane; e < OUT_PX * DL; e += 64) {
+                        const int qq = e & (OUT_PX - 1), jj = e / OUT_PX;
+                        const int jo = jb * DL + jj, xo = x_base + q_base + qq;
+                        if (jo < p.D && xo < p.w)
+                            p.cost[(size_t)b * p.cost_bstride + (size_t)jo * hw + (size_t)y * p.w + xo] = outb[qq * DL + jj];
+                    }
+                }
+                fwave_lds_fence();
+            }
+        }
+    }
+}
+
+template <int DL>
+static size_t fast_lds_bytes(const CvParams& p) { return (size_t)4 * (p.V * 512 + 16 + 1024 + 272 + (p.cost_hi ? 0 : 8 * DL * 4)); }
+
+template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU, int MF, int KS>
+static hipError_t launch_fast(const CvParams& p, hipStream_t stream) {
+    const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
+    if (p.gate_bits) hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 2, KS>), grid, block, fast_lds_bytes<DL>(p), stream, p);
+    else hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF, KS>), grid, block, fast_lds_bytes<DL>(p), stream, p);
+    return hipGetLastError();
+}
+
+template <typename FeatT, int CPL, bool FULL, int LPU, int MF, int KS>
+static hipError_t launch_fast_c(const CvParams& p, hipStream_t stream) {
+    if (p.D <= 8)       return launch_fast<FeatT, 8, CPL, FULL, 4, LPU, 0, 1>(p, stream);
+    else if (p.D <= 16) return launch_fast<FeatT, 16, CPL, FULL, 4, LPU, 0, 1>(p, stream);
+    else if (p.D <= 32) return launch_fast<FeatT, 32, CPL, FULL, 4, LPU, 0, 1>(p, stream);
+    if constexpr (sizeof(FeatT) == 4) return launch_fast<FeatT, 64, CPL, FULL, 6, LPU, 0, 1>(p, stream);
+    else return launch_fast<FeatT, 64, CPL, FULL, 8, LPU, MF, KS>(p, stream);
+}
+
+// Production matcher: fused candidate sampling only (no explicit d_volume), mode 0, no stats counters.
+hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled) {
+    *handled = false;
+    if (p.d_volume || p.mode_f || p.stats) return hipSuccess;
+    const size_t esz = p.feat_bf16 ? 2 : 4;
+    if ((size_t)(p.h + 2) * (p.w + 2) >= ((size_t)1 << 24)) return hipSuccess;               // 24-bit texel index
+    if ((size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets
+    if (fast_lds_bytes<64>(p) > 64 * 1024) return hipSuccess;                                 // absurd V
+    const int nchunk = (int)(p.F * esz / 16);
+    const bool no_mfma = (p.ablate & 1) != 0;                                                 // dev: VALU correlation for A/B timing
+    *handled = true;
+    if (p.feat_bf16) {
+        if (nchunk == 8 && !no_mfma) return launch_fast_c<uint16_t, 2, true, 4, 1, 2>(p, stream);   // F = 64: matrix-pipe correlation at D > 32
+        if (nchunk == 8)  return launch_fast_c<uint16_t, 2, true, 4, 0, 1>(p, stream);       // F = 64: 4 lanes x 32 B per (item, tap) unit
+        if (nchunk == 4 && !no_mfma) return launch_fast_c<uint16_t, 1, false, 8, 1, 1>(p, stream);  // F = 32
+        if (nchunk == 16 && !no_mfma) return launch_fast_c<uint16_t, 2, true, 8, 1, 4>(p, stream);  // F = 128
+        if (nchunk <= 8)  return launch_fast_c<uint16_t, 1, false, 8, 0, 1>(p, stream);
+        if (nchunk <= 16) return launch_fast_c<uint16_t, 2, false, 8, 0, 1>(p, stream);
+    } else {
+        if (nchunk == 16) return launch_fast_c<float, 2, true, 8, 0, 1>(p, stream);          // F = 64
+        if (nchunk <= 8)  return launch_fast_c<float, 1, false, 8, 0, 1>(p, stream);
+        if (nchunk <= 16) return launch_fast_c<float, 2, false, 8, 0, 1>(p, stream);
+        if (nchunk <= 32) return launch_fast_c<float, 4, false, 8, 0, 1>(p, stream);
+    }
+    *handled = false;                                                                         // very wide F: exact kernels
+    return hipSuccess;
+}
+
+}  // namespace magnet

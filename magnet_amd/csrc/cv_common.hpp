@@ -33,6 +33,7 @@ struct CvParams {
     uint16_t*      cost_hi;           // optional split-bf16 channel-last output (see include/magnet_hip.h)
     uint16_t*      cost_lo;
     long long      cost_ld;
+    uint8_t*       gate_bits;         // optional debug output (B,V,D,h,w)
     float k[MAGNET_MAX_CANDIDATES];   // (float)k_j, read with wave-uniform indices (scalar loads)
 };
 
@@ -65,6 +66,7 @@ __device__ __forceinline__ void tile_of_block(const CvParams& p, int& tile, int&
 hipError_t launch_cv_generic(const CvParams& p, hipStream_t stream);
 hipError_t launch_cv_worklist(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cv_cand(const CvParams& p, hipStream_t stream, bool* handled);
+hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cvf_bwd(const CvParams& p, const float* gout, float* grad_ref, float* grad_src, hipStream_t stream,
                           bool* handled);
 

@@ -99,7 +99,7 @@ class CostVolumeCW:
         self.kappa = float(thres)
         self.path = path
 
-    def __call__(self, ref_gmm=None, k_list=None, d_volume=None, out=None, stats=None, out_split=None):
+    def __call__(self, ref_gmm=None, k_list=None, d_volume=None, out=None, stats=None, out_split=None, gate_bits=None):
         if d_volume is not None:
             d_volume = d_volume.detach().float().contiguous()
         if ref_gmm is not None:
@@ -110,7 +110,8 @@ class CostVolumeCW:
             e0.record()
         res = lib.cost_volume_cw(self.ref_cl, self.src_pad, self.src_gmm_pad, self.poses, self.is_valid,
                                  self.intM, self.rays, self.kappa, ref_gmm=ref_gmm, k_list=k_list,
-                                 d_volume=d_volume, out=out, path=self.path, stats=stats, out_split=out_split)
+                                 d_volume=d_volume, out=out, path=self.path, stats=stats, out_split=out_split,
+                                 gate_bits=gate_bits)
         if sink is not None:
             e1.record()
             sink.append((e0, e1))

@@ -44,6 +44,7 @@ class MagnetCostVolumeArgs(ctypes.Structure):
         ("cost_batch_stride", ctypes.c_int64),
         ("cost_hi", ctypes.c_void_p), ("cost_lo", ctypes.c_void_p), ("cost_ld", ctypes.c_int64),
         ("mode", ctypes.c_int32),
+        ("gate_bits", ctypes.c_void_p),
     ]
 
 
@@ -148,7 +149,7 @@ def pack_gmm(gmm_nchw: torch.Tensor, out: torch.Tensor | None = None):
 
 def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM, rays, kappa,
                    ref_gmm=None, k_list=None, d_volume=None, out=None, path: int = 0, stats=None, out_split=None,
-                   mode: int = 0):
+                   mode: int = 0, gate_bits=None):
     """Launch the fused matching kernel.  All tensors on one GPU; see MagnetCostVolumeArgs.
 
     ref_feat_cl (B,h,w,F) from pack_features(pad=0); src_feat_pad (V*B,h+2,w+2,F) from
@@ -224,6 +225,12 @@ def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM
     a.path = int(path)
     if stats is not None:
         a.stats = _dev(stats, "stats").data_ptr()
+    if gate_bits is not None:
+        # debug output: (B,V,D,h,w) uint8 consistency-gate bits (zero it first: invalid views are not written)
+        if not gate_bits.is_cuda or gate_bits.dtype != torch.uint8 or tuple(gate_bits.shape) != (B, V, D, h, w) \
+                or not gate_bits.is_contiguous():
+            raise MagnetError(f"gate_bits must be a contiguous uint8 GPU tensor of shape {(B, V, D, h, w)}")
+        a.gate_bits = gate_bits.data_ptr()
     for t in (s, g, po, iv, K, ry):
         if t.device != r.device:
             raise MagnetError("all tensors must be on the same device")

@@ -229,7 +229,7 @@ class MAGNET(nn.Module):
             main.wait_event(ev_pack)
             partial = g_stack.run_invariant(gin_hi, gin_lo, ctot, rows, wp, work, Dp)
         for _ in range(n_iter):
-            if self.matcher_path in (0, 2):
+            if self.matcher_path in (0, 2, 4):
                 # the candidate-lane kernel writes the D cost channels of the G-Net input buffer directly
                 matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out_split=(gin_hi, gin_lo, ctot))  # MAGNET.py:153-164
             else:

@@ -1,0 +1,226 @@
+"""-m gpu: the PRODUCTION matcher (cost_volume_fast.hip, `path` 0/4) — tolerance parity against the oracle.
+
+The production kernel does not reproduce the reference's fp32 rounding sequence (homography.py:131-148): parity is
+(a) gate-flip fraction <= 1e-5 against the oracle's gate bits (homography.py:157-158), read back through the ABI's
+`gate_bits` debug output, (b) |hip - oracle| <= 2e-5 + 2e-5 |oracle| on every entry none of whose gates flipped,
+(c) abs_rel of the refinement loop's depth < 1e-4 (north_star).  The exact kernels (path 1/2/3) keep their bitwise /
+zero-flip tests in test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from magnet_amd import synth
+from oracle import oracle
+from tests.parity import assert_tolerant_parity, oracle_cost, to_dev
+from tests.stubs import StubDNet, StubFNet, make_args, seeded_magnet_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(inp, k_list, device, feat_dtype="fp32", path=4, want_gates=True, kappa=5):
+    from magnet_amd.homography import CostVolumeCW
+    d = to_dev(inp, device)
+    cv = CostVolumeCW(d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"],
+                      d["cam_intrins"], kappa, feat_dtype=feat_dtype, path=path)
+    B, F, h, w = inp["ref_feat"].shape
+    V = inp["nghbr_feat"].shape[0] // B
+    gates = torch.zeros(B, V, len(k_list), h, w, dtype=torch.uint8, device=device) if want_gates else None
+    cost = cv(ref_gmm=d["ref_gmms"], k_list=k_list, gate_bits=gates)
+    return cost, gates
+
+
+def _check(inp, k, gpu, fdt="fp32", label="", path=4):
+    orc, og, _ = oracle_cost(inp, k, aux=True)
+    cost, gates = _run(inp, k, gpu, feat_dtype=fdt, path=path)
+    st = assert_tolerant_parity(cost, orc, gates, og, label=label)
+    # the production launch (no debug output) is a different template instance: it must give the same volume
+    plain, _ = _run(inp, k, gpu, feat_dtype=fdt, path=path, want_gates=False)
+    assert torch.equal(plain, cost), f"{label}: gate-bit instance and production instance differ"
+    return st
+
+
+def _golden_tiny(g):
+    return dict(ref_feat=torch.from_numpy(g["G2_ref_feat"]), nghbr_feat=torch.from_numpy(g["G2_nghbr_feat"]),
+                ref_gmms=torch.from_numpy(g["G2_ref_gmms"]), nghbr_gmms=torch.from_numpy(g["G2_nghbr_gmms"]),
+                nghbr_poses=torch.from_numpy(g["G2_nghbr_poses"]), is_valid=torch.from_numpy(g["G2_is_valid"]),
+                cam_intrins={"intM": torch.from_numpy(g["G2_intM"]), "unit_ray_array_2D": torch.from_numpy(g["G2_rays"])})
+
+
+def test_fast_tiny_golden(hip_lib, gpu, golden):
+    """The reference's own output on the edge-case vector (invalid view, behind-camera pose, out of bounds)."""
+    inp = _golden_tiny(golden)
+    cost, _ = _run(inp, list(golden["G1_k_D5"]), gpu, want_gates=False)
+    assert_tolerant_parity(cost, golden["G2_cost"], n_views=2, label="tiny golden (reference output)")
+    _check(inp, list(golden["G1_k_D5"]), gpu, label="tiny golden")
+
+
+def test_fast_gate_bits_match_reference_G3(hip_lib, gpu, golden):
+    """G3 = the non-zero pattern of the reference's `_compute_cost_CW` output (= its gate bits wherever the feature cost is
+    non-zero) for every valid (b, v) of the tiny vector: the `gate_bits` output of both candidate-lane kernels must
+    reproduce it — the exact kernel bit for bit, the production matcher up to one flipped gate."""
+    inp = _golden_tiny(golden)
+    ref = golden["G3_gate_nonzero"].astype(bool)                                   # (B,V,D,h,w), zeros for the invalid view
+    _, g_fast = _run(inp, list(golden["G1_k_D5"]), gpu, path=4)
+    _, g_exact = _run(inp, list(golden["G1_k_D5"]), gpu, path=2)
+    assert np.array_equal(g_exact.cpu().numpy().astype(bool), ref)
+    assert int((g_fast.cpu().numpy().astype(bool) != ref).sum()) <= 1
+
+
+def test_fast_C1_golden_subsample(hip_lib, gpu, golden):
+    wl = synth.WORKLOADS["C1"]
+    inp = synth.make_inputs(wl, B=1, seed=0)
+    cost, _ = _run(inp, list(golden["G1_k_D16"]), gpu, want_gates=False)
+    assert_tolerant_parity(cost.cpu().numpy()[:, :, ::5, ::7], golden["G2_C1_cost_sub"], n_views=2, label="C1 golden")
+
+
+CASES = [
+    # name, workload, B, seed, feat_dtype, invalid
+    ("C1", "C1", 1, 0, "fp32", ()),
+    ("C1-b2-invalid", "C1", 2, 1, "fp32", ((0, 1),)),
+    ("C2-fp32", "C2", 1, 0, "fp32", ()),
+    ("C2-bf16", "C2", 2, 1, "bf16", ((1, 2),)),
+    ("C4", "C4", 1, 0, "fp32", ()),
+    ("C5", "C5", 1, 2, "fp32", ()),
+    ("shipped-D5", "shipped", 2, 0, "fp32", ()),
+]
+
+
+@pytest.mark.parametrize("name,wlname,B,seed,fdt,invalid", CASES)
+def test_fast_vs_oracle_baseline_shapes(hip_lib, gpu, name, wlname, B, seed, fdt, invalid):
+    """Every BASELINE.json shape: gate-flip fraction <= 1e-5, value tolerance elsewhere."""
+    wl = synth.WORKLOADS[wlname]
+    inp = synth.make_inputs(wl, B=B, seed=seed, invalid=list(invalid), round_bf16=(fdt == "bf16"))
+    _check(inp, oracle.depth_sampling(3, wl.D), gpu, fdt=fdt, label=name)
+
+
+def test_fast_vector_alu_correlation_variant(hip_lib, gpu):
+    """bf16 F = 64: dev bit 8 moves the channel contraction from the matrix pipe to v_dot2c; same gates, same tolerance."""
+    wl = synth.WORKLOADS["C2"]
+    inp = synth.make_inputs(wl, B=1, seed=5, round_bf16=True)
+    k = oracle.depth_sampling(3, wl.D)
+    _check(inp, k, gpu, fdt="bf16", label="C2 valu-corr", path=4 | 0x100)
+    a, ga = _run(inp, k, gpu, feat_dtype="bf16", path=4)
+    b, gb = _run(inp, k, gpu, feat_dtype="bf16", path=4 | 0x100)
+    assert torch.equal(ga, gb)
+    assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_fast_ragged_grid_and_odd_D(hip_lib, gpu):
+    wl = synth.Workload("ragged", "scannet", 13, 19, V=1, D=7, F=8)
+    inp = synth.make_inputs(wl, B=3, seed=4)
+    _check(inp, oracle.depth_sampling(3, wl.D), gpu, label="ragged")
+
+
+@pytest.mark.parametrize("V,D,F,fdt", [(6, 24, 32, "bf16"), (1, 256, 8, "fp32"), (3, 40, 128, "fp32"), (2, 9, 128, "bf16"),
+                                        (8, 16, 72, "fp32"), (3, 64, 32, "bf16"), (2, 130, 128, "bf16"), (5, 70, 64, "bf16"),
+                                        (2, 64, 48, "bf16")])
+def test_fast_shape_sweep(hip_lib, gpu, V, D, F, fdt):
+    """Channel counts off the F = 64 path, several candidate blocks, matrix-pipe correlation with 1 / 2 / 4 K steps."""
+    wl = synth.Workload("sweep", "7scenes", 10, 23, V=V, D=D, F=F)
+    inp = synth.make_inputs(wl, B=2, seed=V * 100 + D, round_bf16=(fdt == "bf16"), invalid=[(1, 0)])
+    _check(inp, oracle.depth_sampling(3, D), gpu, fdt=fdt, label=f"sweep V={V} D={D} F={F} {fdt}")
+
+
+def test_fast_nan_and_degenerate_inputs(hip_lib, gpu):
+    """NaN / zero sigma / zero depth in the reference gmm and a singular pose (test_gpu_parity.py's case)."""
+    wl = synth.Workload("nan", "scannet", 12, 16, V=2, D=8, F=8)
+    inp = synth.make_inputs(wl, B=2, seed=21)
+    inp["ref_gmms"][0, 0, 3, 4] = float("nan")
+    inp["ref_gmms"][0, 1, 5, 6] = float("nan")
+    inp["ref_gmms"][1, 1, 2, :] = 0.0
+    inp["ref_gmms"][1, 0, 7, :] = 0.0
+    inp["nghbr_poses"][1, 1, :3, :3] = 0.0
+    _check(inp, oracle.depth_sampling(3, 8), gpu, label="nan/degenerate")
+
+
+def test_fast_all_views_invalid_is_zero(hip_lib, gpu):
+    wl = synth.Workload("inv", "scannet", 12, 16, V=2, D=5, F=8)
+    inp = synth.make_inputs(wl, B=1, seed=5, invalid=[(0, 0), (0, 1)])
+    got, _ = _run(inp, oracle.depth_sampling(3, 5), gpu, want_gates=False)
+    assert torch.count_nonzero(got) == 0
+
+
+def test_fast_auto_path_selects_production_matcher(hip_lib, gpu):
+    """path 0 = production matcher for fused sampling; with an explicit d_volume it must fall to the exact kernel."""
+    from magnet_amd.homography import CostVolumeCW
+    wl = synth.Workload("sel", "scannet", 24, 32, V=2, D=16, F=16)
+    inp = synth.make_inputs(wl, B=1, seed=9)
+    k = oracle.depth_sampling(3, wl.D)
+    a, _ = _run(inp, k, gpu, path=0, want_gates=False)
+    b, _ = _run(inp, k, gpu, path=4, want_gates=False)
+    assert torch.equal(a, b)
+    d = to_dev(inp, gpu)
+    cv0 = CostVolumeCW(d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"], d["cam_intrins"], 5, path=0)
+    cv2 = CostVolumeCW(d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"], d["cam_intrins"], 5, path=2)
+    dv = synth.depth_volume_from_gmm(inp["ref_gmms"], k).to(gpu)
+    assert torch.equal(cv0(d_volume=dv), cv2(d_volume=dv))
+    from magnet_amd import lib
+    cv4 = CostVolumeCW(d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"], d["cam_intrins"], 5, path=4)
+    with pytest.raises(lib.MagnetError, match="production matcher needs fused sampling"):
+        cv4(d_volume=dv)
+
+
+def test_fast_split_output_equals_dense(hip_lib, gpu):
+    """cost_hi/cost_lo written by the production matcher = split of its own fp32 volume (D = 64 matrix-pipe form, D = 5)."""
+    from magnet_amd.convnet import split_bf16
+    from magnet_amd.homography import CostVolumeCW
+    for D, F, fdt in ((64, 64, "bf16"), (5, 8, "fp32")):
+        wl = synth.Workload("sp", "scannet", 13, 19, V=2, D=D, F=F)
+        inp = synth.make_inputs(wl, B=2, seed=11, round_bf16=(fdt == "bf16"))
+        d = to_dev(inp, gpu)
+        k = oracle.depth_sampling(3, D)
+        cv = CostVolumeCW(d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"], d["cam_intrins"], 5,
+                          feat_dtype=fdt, path=4)
+        dense = cv(ref_gmm=d["ref_gmms"], k_list=k)
+        ld = 96
+        hi = torch.full((2 * 15 * 21, ld), 7.0, dtype=torch.bfloat16, device=gpu); lo = torch.full_like(hi, 7.0)
+        cv(ref_gmm=d["ref_gmms"], k_list=k, out_split=(hi, lo, ld))
+        eh, el = split_bf16(dense.permute(0, 2, 3, 1).contiguous())
+        hi4 = hi.view(2, 15, 21, ld); lo4 = lo.view(2, 15, 21, ld)
+        assert torch.equal(hi4[:, 1:-1, 1:-1, :D], eh) and torch.equal(lo4[:, 1:-1, 1:-1, :D], el)
+        poison = torch.full((1,), 7.0, dtype=torch.bfloat16, device=gpu)
+        assert torch.all(hi4[:, 1:-1, 1:-1, D:] == poison) and torch.all(hi4[:, 0] == poison) and torch.all(lo4[:, :, -1] == poison)
+
+
+def test_fast_batch_independence_at_bench_size(hip_lib, gpu):
+    """64 frames per launch (bench.py's step): every frame equals the same frame run alone (no cross-frame state, XCD remap
+    bijective), and frames 0 / 63 are within tolerance of the oracle."""
+    wl = synth.WORKLOADS["C2"]
+    inp = synth.make_inputs(wl, B=64, seed=1234, round_bf16=True)
+    k = oracle.depth_sampling(3, wl.D)
+    full, _ = _run(inp, k, gpu, feat_dtype="bf16", path=0, want_gates=False)
+    V = wl.V
+    for b in (0, 31, 63):
+        idx = [v * 64 + b for v in range(V)]
+        one = dict(ref_feat=inp["ref_feat"][b:b + 1], nghbr_feat=inp["nghbr_feat"][idx], ref_gmms=inp["ref_gmms"][b:b + 1],
+                   nghbr_gmms=inp["nghbr_gmms"][idx], nghbr_poses=inp["nghbr_poses"][b:b + 1], is_valid=inp["is_valid"][b:b + 1],
+                   cam_intrins={kk: vv[b:b + 1] for kk, vv in inp["cam_intrins"].items()})
+        alone, _ = _run(one, k, gpu, feat_dtype="bf16", path=0, want_gates=False)
+        assert torch.equal(alone[0], full[b])
+        if b != 31:
+            _check(one, k, gpu, fdt="bf16", label=f"C2 bench-size frame {b}")
+
+
+def test_fast_loop_abs_rel_vs_exact_loop(hip_lib, gpu):
+    """north_star: depth maps within abs_rel 1e-4.  The full refinement loop (C3 shape, I = 3, MFMA convolutions) with the
+    production matcher against the same loop with the exact matcher."""
+    from magnet_amd.magnet import MAGNET
+    wl = synth.WORKLOADS["C3"]
+    args = make_args(D=wl.D, iters=3, dpv_h=wl.h, dpv_w=wl.w)
+    inp = synth.make_inputs(wl, B=2, seed=3, round_bf16=True)
+    outs = {}
+    for path in (0, 2):
+        m = MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2, fdim=wl.F), feat_dtype="bf16")
+        m.matcher_path = path
+        seeded_magnet_weights(m, 3)
+        m = m.to(gpu).eval()
+        g = torch.Generator().manual_seed(0)
+        ref = torch.rand(2, 3, 4 * wl.h, 4 * wl.w, generator=g).to(gpu)
+        ngh = torch.rand(2 * wl.V, 3, 4 * wl.h, 4 * wl.w, generator=g).to(gpu)
+        with torch.no_grad():
+            outs[path] = [o.cpu() for o in m(ref, ngh, inp["nghbr_poses"].to(gpu), inp["is_valid"], inp["cam_intrins"], mode="test")]
+    for a, b in zip(outs[0], outs[2]):
+        mu_a, mu_b = a[:, 0], b[:, 0]
+        abs_rel = float(((mu_a - mu_b).abs() / mu_b.abs().clamp_min(1e-3)).mean())
+        print(f"[loop] abs_rel(production vs exact matcher) = {abs_rel:.3e}")
+        assert abs_rel < 1e-4

@@ -58,7 +58,7 @@ def test_pack_gmm(hip_lib, gpu):
 
 
 # ---- cost volume: golden (reference) vectors -------------------------------------------------------
-@pytest.mark.parametrize("path", [0, 1, 3])
+@pytest.mark.parametrize("path", [2, 1, 3])
 @pytest.mark.parametrize("fused", [True, False])
 def test_cost_volume_tiny_golden(hip_lib, gpu, golden, path, fused):
     """The reference's own output on the edge-case vector (invalid view, behind-camera pose, OOB)."""
@@ -86,7 +86,7 @@ def test_cost_volume_reference_signature(hip_lib, gpu, golden):
 def test_cost_volume_C1_golden_subsample(hip_lib, gpu, golden):
     wl = synth.WORKLOADS["C1"]
     inp = synth.make_inputs(wl, B=1, seed=0)
-    for path in (0, 1, 3):
+    for path in (2, 1, 3):
         got = _hip_cost(inp, list(golden["G1_k_D16"]), gpu, path=path).cpu().numpy()
         assert_cost_parity(got[:, :, ::5, ::7], golden["G2_C1_cost_sub"], path=path, label="C1 golden")
 
@@ -103,7 +103,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("path", [0, 1, 3])
+@pytest.mark.parametrize("path", [2, 1, 3])
 @pytest.mark.parametrize("name,wlname,B,seed,fdt,invalid", CASES)
 def test_cost_volume_vs_oracle(hip_lib, gpu, name, wlname, B, seed, fdt, invalid, path):
     wl = synth.WORKLOADS[wlname]
@@ -120,7 +120,7 @@ def test_cost_volume_kitti_wide_aspect(hip_lib, gpu):
     inp = synth.make_inputs(wl, B=1, seed=0)
     k = oracle.depth_sampling(3, wl.D)
     orc = oracle_cost(inp, k)
-    for path in (0, 1, 3):
+    for path in (2, 1, 3):
         got = _hip_cost(inp, k, gpu, path=path)
         assert_cost_parity(got, orc, path=path, label="C4 kitti")
 
@@ -131,7 +131,7 @@ def test_cost_volume_ragged_grid_and_odd_D(hip_lib, gpu):
     inp = synth.make_inputs(wl, B=3, seed=4)
     k = oracle.depth_sampling(3, wl.D)
     orc = oracle_cost(inp, k)
-    for path in (0, 1, 3):
+    for path in (2, 1, 3):
         got = _hip_cost(inp, k, gpu, path=path)
         assert_cost_parity(got, orc, path=path, label="ragged")
 
@@ -144,7 +144,7 @@ def test_cost_volume_shape_sweep(hip_lib, gpu, V, D, F, fdt):
     inp = synth.make_inputs(wl, B=2, seed=V * 100 + D, round_bf16=(fdt == "bf16"), invalid=[(1, 0)])
     k = oracle.depth_sampling(3, D)
     orc = oracle_cost(inp, k)
-    for path in (0, 1) + ((3,) if D <= 128 else ()):
+    for path in (2, 1) + ((3,) if D <= 128 else ()):
         got = _hip_cost(inp, k, gpu, feat_dtype=fdt, path=path)
         assert_cost_parity(got, orc, path=path, label=f"sweep V={V} D={D} F={F} {fdt}")
 
@@ -162,7 +162,7 @@ def test_cost_volume_nan_and_degenerate_inputs(hip_lib, gpu):
     k = oracle.depth_sampling(3, 8)
     orc = oracle_cost(inp, k)
     assert np.isfinite(orc).all()
-    for path in (0, 1, 3):
+    for path in (2, 1, 3):
         got = _hip_cost(inp, k, gpu, path=path)
         assert_cost_parity(got, orc, path=path, label="nan/degenerate")
 
@@ -170,7 +170,7 @@ def test_cost_volume_nan_and_degenerate_inputs(hip_lib, gpu):
 def test_cost_volume_all_views_invalid_is_zero(hip_lib, gpu):
     wl = synth.Workload("inv", "scannet", 12, 16, V=2, D=5, F=8)
     inp = synth.make_inputs(wl, B=1, seed=5, invalid=[(0, 0), (0, 1)])
-    for path in (0, 1, 3):
+    for path in (2, 1, 3):
         got = _hip_cost(inp, oracle.depth_sampling(3, 5), gpu, path=path)
         assert torch.count_nonzero(got) == 0
 
@@ -205,7 +205,7 @@ def test_cost_volume_strided_output_into_gnet_buffer(hip_lib, gpu):
     wl = synth.Workload("s", "scannet", 12, 16, V=2, D=5, F=8)
     inp = synth.make_inputs(wl, B=2, seed=6)
     k = oracle.depth_sampling(3, 5)
-    for path in (0, 1, 3):
+    for path in (2, 1, 3):
         buf = torch.full((2, 5 + 3, 12, 16), 7.0, device=gpu)
         _hip_cost(inp, k, gpu, out=buf[:, :5], path=path)
         dense = _hip_cost(inp, k, gpu, path=path)
@@ -242,7 +242,7 @@ def test_linearity_in_reference_features(hip_lib, gpu):
     wl = synth.WORKLOADS["C2"]
     inp = synth.make_inputs(wl, B=1, seed=3)
     k = oracle.depth_sampling(3, wl.D)
-    for path in (0, 1, 3):
+    for path in (2, 1, 3):
         a = _hip_cost(inp, k, gpu, feat_dtype="bf16", path=path)
         inp2 = dict(inp); inp2["ref_feat"] = inp["ref_feat"] * 2.0
         b = _hip_cost(inp2, k, gpu, feat_dtype="bf16", path=path)

@@ -1,36 +1,43 @@
 #!/usr/bin/env python3
-"""Dev tool (GPU box): time the fused cost-volume kernel alone under ablations / paths.
-usage: python tools/ablate.py [workload] [frames]"""
+"""Dev tool (GPU box): time the fused cost-volume kernel alone under kernel selection / dev switches (`path`).
+usage: python tools/ablate.py [workload] [frames] [split]      (split: time the split-bf16 channel-last output form)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from magnet_amd import synth, lib
 from magnet_amd.homography import CostVolumeCW
 from magnet_amd.magnet import depth_sampling
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import device_inputs
 
 wl = synth.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "C2"]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+split = len(sys.argv) > 3 and sys.argv[3] == "split"
 dev = torch.device("cuda:0")
 inp = device_inputs(wl, B, 1000, dev)
 k = depth_sampling(3, wl.D)
 out = torch.empty(B, wl.D, wl.h, wl.w, device=dev)
-for fdt in ("bf16",):
-    for name, path in (("cand", 2), ("cand noP2", 0x102), ("cand nogmm", 0x202), ("cand noP2 nogmm", 0x302), ("cand geom only", 0x802), ("cand geom only nogmm", 0xA02)):
-        cv = CostVolumeCW(inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"], inp["is_valid"],
-                          inp["cam_intrins"], 5, feat_dtype=fdt, path=path)
-        stats = torch.zeros(4, dtype=torch.int32, device=dev)
-        cv(ref_gmm=inp["ref_gmms"], k_list=k, out=out, stats=stats)
-        torch.cuda.synchronize()
-        n = 3 if path == 1 else 10
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            cv(ref_gmm=inp["ref_gmms"], k_list=k, out=out)
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / n
-        st = stats.cpu().tolist()
-        gbs = wl.algorithmic_bytes() * B / (ms * 1e-3) / 1e9 if fdt == wl.feat_dtype else float("nan")
-        print(f"{wl.name} B={B} {fdt:5s} {name:12s}: {ms:8.3f} ms/launch  {1e3*ms/B:8.2f} us/frame  alg {gbs:7.1f} GB/s  "
-              f"tiles wl/gen {st[0]}/{st[1]} items {st[2]} ({st[2]/max(1,B*wl.hw*wl.V):.2f} per pixel-view)")
+ld = (wl.D + 7) // 8 * 8 + 256
+hi = torch.zeros(B * (wl.h + 2) * (wl.w + 2), ld, dtype=torch.bfloat16, device=dev); lo = torch.zeros_like(hi)
+fdt = wl.feat_dtype
+VARIANTS = (("production (auto)", 0), ("production, VALU correlation", 0x104), ("exact cand", 2), ("exact cand noP2", 0x102),
+            ("exact cand geom only", 0x802), ("exact worklist", 3))
+for name, path in VARIANTS:
+    if split and (path & 0xff) == 3:
+        continue
+    cv = CostVolumeCW(inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"], inp["is_valid"],
+                      inp["cam_intrins"], 5, feat_dtype=fdt, path=path)
+    kw = dict(out_split=(hi, lo, ld)) if split else dict(out=out)
+    try:
+        cv(ref_gmm=inp["ref_gmms"], k_list=k, **kw)
+    except lib.MagnetError as e:
+        print(f"{wl.name} {name}: {e}"); continue
+    torch.cuda.synchronize()
+    n = 20
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        cv(ref_gmm=inp["ref_gmms"], k_list=k, **kw)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    gbs = wl.algorithmic_bytes() * B / (ms * 1e-3) / 1e9
+    print(f"{wl.name} B={B} {fdt:5s} {'split' if split else 'nchw '} {name:30s}: {ms:8.3f} ms/launch  alg {gbs:7.1f} GB/s = {gbs / 80:5.1f} % of 8 TB/s")
