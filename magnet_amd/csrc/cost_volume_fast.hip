@@ -28,49 +28,9 @@
 //   * no fp64, no exec-mask branches around the gate / combine
 // Everything that needs the reference's exact rounding (explicit d_volume, est_costvolume_F mode, stats) stays in
 // cost_volume_cand.hip / cost_volume.hip.
-#include "cv_common.hpp"
+#include "cv_fast_common.hpp"
 
 namespace magnet {
-
-typedef __attribute__((ext_vector_type(2))) __bf16 fbf16x2_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 fbf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float ff32x4_t;
-
-__device__ __forceinline__ float fdot_chunk(const uint4 a, const uint4 b, float acc, uint16_t) {
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fbf16x2_t, a.x), __builtin_bit_cast(fbf16x2_t, b.x), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fbf16x2_t, a.y), __builtin_bit_cast(fbf16x2_t, b.y), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fbf16x2_t, a.z), __builtin_bit_cast(fbf16x2_t, b.z), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fbf16x2_t, a.w), __builtin_bit_cast(fbf16x2_t, b.w), acc, false);
-    return acc;
-}
-__device__ __forceinline__ float fdot_chunk(const uint4 a, const uint4 b, float acc, float) {
-    acc = __builtin_fmaf(__uint_as_float(a.x), __uint_as_float(b.x), acc);
-    acc = __builtin_fmaf(__uint_as_float(a.y), __uint_as_float(b.y), acc);
-    acc = __builtin_fmaf(__uint_as_float(a.z), __uint_as_float(b.z), acc);
-    acc = __builtin_fmaf(__uint_as_float(a.w), __uint_as_float(b.w), acc);
-    return acc;
-}
-
-__device__ __forceinline__ float freduce8(float v) {    // sum over aligned groups of 8 lanes
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
-    return v;
-}
-__device__ __forceinline__ float freduce4(float v) {    // sum over aligned groups of 4 lanes
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
-    return v;
-}
-
-__device__ __forceinline__ void fwave_lds_fence() {
-    // LDS operations of one wave execute in order; only the compiler must not reorder across this.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-constexpr uint32_t FKEY_CLOSED = 0xffffffffu;
 
 // DL   = candidates per pixel group inside a wave (8,16,32,64); PPW = 64/DL pixels per iteration
 // CPL  = 16-byte channel chunks per lane in the VALU correlation (F*sizeof(FeatT)/16 <= LPU*CPL), FULL = exactly
@@ -81,6 +41,9 @@ template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU, int OPT
 __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
     constexpr bool MFMA = (OPT & 1) != 0;
     constexpr bool GBITS = (OPT & 2) != 0;
+    constexpr bool NOGMM = (OPT & 4) != 0;               // dev timing ablation: no (mu,sigma) taps, pseudo gate
+    constexpr bool NOCORR = (OPT & 8) != 0;              // dev timing ablation: no feature loads / dot products
+    constexpr bool LEAD = (OPT & 16) != 0;               // (mu,sigma) taps loaded by the first lane of each run of equal quads, shared through LDS
     constexpr int IPP = MFMA ? 4 : 64 / (4 * LPU);        // items per correlation pass
     constexpr int CSTR = LPU * 16;                        // byte stride between a lane's channel chunks (VALU correlation)
     constexpr int PPW = 64 / DL;
@@ -102,12 +65,13 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
     // ---- wave-private LDS ----
     constexpr int OUT_PX = 8;                             // pixels staged before a coalesced flush (32-byte row segments)
     const int out_bytes = p.cost_hi ? 0 : OUT_PX * DL * 4;
-    const int wave_bytes = p.V * 512 + 16 + 1024 + 272 + out_bytes;
+    const int wave_bytes = p.V * 512 + 16 + 1024 + 272 + out_bytes + (LEAD ? 2048 + 32 : 0);
     unsigned char* wbase = smem + wv * wave_bytes;
     float4*   pvtab = reinterpret_cast<float4*>(wbase);                               // [V][16 px][2]
     float4*   ctab  = reinterpret_cast<float4*>(wbase + p.V * 512);                   // [zero slot for closed lanes | 64 items] x 4 taps
     uint32_t* items = reinterpret_cast<uint32_t*>(wbase + p.V * 512 + 16 + 1024);     // [64 + pad]
     float*    outb  = reinterpret_cast<float*>(wbase + p.V * 512 + 16 + 1024 + 272);  // [OUT_PX][DL] results of one block
+    float4*   gslot = reinterpret_cast<float4*>(wbase + p.V * 512 + 16 + 1024 + 272 + out_bytes);   // LEAD: [1 + 64 runs][2] taps
 
     // ---- depth-linear projection terms for the wave's 16 pixels x V views (once per tile row) ----
     for (int e = lane; e < 16 * p.V; e += 64) {
@@ -203,13 +167,29 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                 const bool inwin = (__float_as_uint(ixs) < xlim) && (__float_as_uint(iys) < ylim);
                 const uint32_t qi = inwin ? (uint32_t)__mul24((int)y0f, Wp) + (uint32_t)(int)x0f : 0u;   // quad origin, padded map
                 // ---------------- (mu,sigma) taps + consistency gate ----------------
-                const float4 g0 = *reinterpret_cast<const float4*>(sgm + qi * 8u);                 // (mu,sg) x0, x0+1 of row y0
-                const float4 g1 = *reinterpret_cast<const float4*>(sgm + (qi + (uint32_t)Wp) * 8u);
+                float4 g0 = make_float4(0.f, 1.f, 0.f, 1.f), g1 = g0;
+                if (LEAD) {
+                    const uint32_t tkey = inwin ? qi : FKEY_CLOSED;
+                    const uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);
+                    const bool lead = inwin && (tkey != tprev);
+                    const unsigned long long lbal = __ballot(lead);
+                    const int run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lbal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lbal, lead ? 1u : 0u));
+                    if (lead) {
+                        gslot[run * 2 + 0] = *reinterpret_cast<const float4*>(sgm + qi * 8u);
+                        gslot[run * 2 + 1] = *reinterpret_cast<const float4*>(sgm + (qi + (uint32_t)Wp) * 8u);
+                    }
+                    fwave_lds_fence();
+                    g0 = gslot[run * 2 + 0]; g1 = gslot[run * 2 + 1];
+                } else if (!NOGMM) {
+                    g0 = *reinterpret_cast<const float4*>(sgm + qi * 8u);                 // (mu,sg) x0, x0+1 of row y0
+                    g1 = *reinterpret_cast<const float4*>(sgm + (qi + (uint32_t)Wp) * 8u);
+                }
                 float mu_w = g0.x * wnw, sg_w = g0.y * wnw;
                 mu_w = __builtin_fmaf(g0.z, wne, mu_w); sg_w = __builtin_fmaf(g0.w, wne, sg_w);
                 mu_w = __builtin_fmaf(g1.x, wsw, mu_w); sg_w = __builtin_fmaf(g1.y, wsw, sg_w);
                 mu_w = __builtin_fmaf(g1.z, wse, mu_w); sg_w = __builtin_fmaf(g1.w, wse, sg_w);
-                const bool gate = inwin && (__builtin_fabsf(zw - mu_w) < sg_w * kappa);          // homography.py:157-158
+                bool gate = inwin && (__builtin_fabsf(zw - mu_w) < sg_w * kappa);                // homography.py:157-158
+                if (NOGMM) gate = inwin && ((j0 & 7) < 5) && (zw > sg_w);
                 if (GBITS && live)
                     p.gate_bits[(((size_t)b * p.V + v) * p.D + j) * hw + (size_t)y * p.w + x] = gate ? 1 : 0;
 
@@ -228,7 +208,8 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                 fwave_lds_fence();
 
                 // ---------------- correlation ----------------
-                if (MFMA) {
+                if (NOCORR) {
+                } else if (MFMA) {
                     // rows of A = (item of the pass, tap); B = the pixel's reference vector in every column: lane group g4 = lane >> 4
                     // ends up with C[reg t] = <ref, src[item g4, tap t]>
                     for (int ps = 0; ps < nitems; ps += 4) {
@@ -288,7 +269,7 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                     c = __builtin_fmaf(c4.y, wne, c);
                     c = __builtin_fmaf(c4.z, wsw, c);
                     c = __builtin_fmaf(c4.w, wse, c);
-                    acc += c;                                                     // homography.py:159,116 (fp32 here)
+                    acc += gate ? c : 0.f;                                        // homography.py:159,116 (fp32 here); the weights of a closed lane may be NaN
                 }
                 fwave_lds_fence();                                                // ctab/items are rewritten by the next view
             }
@@ -328,6 +309,14 @@ static size_t fast_lds_bytes(const CvParams& p) { return (size_t)4 * (p.V * 512 
 template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU, int MF, int KS>
 static hipError_t launch_fast(const CvParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
+    if constexpr (DL == 64 && sizeof(FeatT) == 2 && KS <= 2 && FULL) {                      // dev timing variants (C2 shape only)
+        const int dv = (p.ablate >> 1) & 0xf;                                                 // path bits 9..12
+        const size_t lds = fast_lds_bytes<DL>(p);
+        if (dv == 1) { hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 4, KS>), grid, block, lds, stream, p); return hipGetLastError(); }
+        if (dv == 2) { hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 8, KS>), grid, block, lds, stream, p); return hipGetLastError(); }
+        if (dv == 3) { hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 12, KS>), grid, block, lds, stream, p); return hipGetLastError(); }
+        if (dv == 8) { hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 16, KS>), grid, block, lds + 4 * 2080, stream, p); return hipGetLastError(); }
+    }
     if (p.gate_bits) hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 2, KS>), grid, block, fast_lds_bytes<DL>(p), stream, p);
     else hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF, KS>), grid, block, fast_lds_bytes<DL>(p), stream, p);
     return hipGetLastError();
@@ -350,11 +339,16 @@ hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled) 
     if ((size_t)(p.h + 2) * (p.w + 2) >= ((size_t)1 << 24)) return hipSuccess;               // 24-bit texel index
     if ((size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets
     if (fast_lds_bytes<64>(p) > 64 * 1024) return hipSuccess;                                 // absurd V
+    if (p.ablate == 0 || (p.ablate & 0x40)) {                                                 // (bit 15 with bit 14: fast64 dev variant)                                                 // D > 32: views batched per pixel (cost_volume_fast64.hip)
+        const hipError_t e = launch_cv_fast64(p, stream, handled);
+        if (e != hipSuccess || *handled) return e;
+    }
     const int nchunk = (int)(p.F * esz / 16);
-    const bool no_mfma = (p.ablate & 1) != 0;                                                 // dev: VALU correlation for A/B timing
+    const bool no_mfma = (p.ablate & 1) == 0;                                                 // dev bit 8: correlation on the matrix pipe (measured slower)
     *handled = true;
     if (p.feat_bf16) {
         if (nchunk == 8 && !no_mfma) return launch_fast_c<uint16_t, 2, true, 4, 1, 2>(p, stream);   // F = 64: matrix-pipe correlation at D > 32
+        if (nchunk == 8 && (p.ablate & 0x20)) return launch_fast_c<uint16_t, 1, true, 8, 0, 1>(p, stream);   // dev bit 13: 8 lanes x 16 B per unit
         if (nchunk == 8)  return launch_fast_c<uint16_t, 2, true, 4, 0, 1>(p, stream);       // F = 64: 4 lanes x 32 B per (item, tap) unit
         if (nchunk == 4 && !no_mfma) return launch_fast_c<uint16_t, 1, false, 8, 1, 1>(p, stream);  // F = 32
         if (nchunk == 16 && !no_mfma) return launch_fast_c<uint16_t, 2, true, 8, 1, 4>(p, stream);  // F = 128

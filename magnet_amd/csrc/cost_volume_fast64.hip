@@ -1,0 +1,387 @@
+// cost_volume_fast64.hip — production matcher for D > 32 (one reference pixel per wave iteration, lane = candidate):
+// the source VIEWS of a pixel are processed in groups of VG, phase by phase, instead of one after the other.
+//
+// Why.  Counters and ablations of the per-view kernel (cost_volume_fast.hip, profiles/r2/): it is neither VALU- nor
+// HBM-bound — 86 % of the wave cycles are s_waitcnt.  Each (pixel, view) iteration is a chain of dependent round trips
+// (projection table from LDS -> geometry -> (mu,sigma) taps from L2 -> gate -> item list through LDS -> feature texels
+// from L2 -> dot products -> result table through LDS -> combine) and a wave has exactly one of them in flight; with the
+// synthetic inputs of SURVEY.md §8d (per-pixel independent depths) every (item, tap) is a different 128-byte line, so the
+// kernel moves ~8.8 GB per launch from the L2s to the L1s and needs many more loads in flight than 8 waves x 1 provide
+// ("no correlation" ablation: 0.46 ms of 1.09 ms).  Here the VG views of a pixel run their geometry / tap loads / gates
+// back to back (independent chains, interleaved by the compiler), their open quads go into ONE item list, the (item, tap)
+// dot products of the whole group are fetched in batches of up to 16 items (8 x 1 KiB loads in flight per wave), then the
+// VG bilinear combines run: two memory round trips per GROUP instead of two per view.
+//
+// Arithmetic, tolerance contract, layouts: exactly cost_volume_fast.hip (see its header).
+#include "cv_fast_common.hpp"
+
+namespace magnet {
+
+// CPL / FULL / LPU: as in cv_fast_kernel (VALU correlation units of LPU lanes x CPL 16-byte chunks)
+// VG = views per group (1..4); GBITS = write the gate bits (debug / parity tests)
+template <typename FeatT, int CPL, bool FULL, int MINW, int LPU, int VG, int GBITS_>
+__global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) {
+    constexpr int DL = 64;
+    constexpr bool GBITS = (GBITS_ & 1) != 0;
+    constexpr bool LEAD = (GBITS_ & 2) != 0;           // (mu,sigma) taps loaded once per run of equal quads, shared through LDS
+    constexpr int IPP = 64 / (4 * LPU);                   // items per correlation pass
+    constexpr int NPASS = 16 / IPP > 4 ? 4 : 16 / IPP;    // passes fetched together (<= 16 items, <= 4 passes)
+    constexpr int CSTR = LPU * 16;                        // byte stride between a lane's channel chunks
+    constexpr int CAP = 64;                               // item capacity of the LDS tables
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_v, b_v;
+    tile_of_block(p, tile_v, b_v);
+    const int tile = __builtin_amdgcn_readfirstlane(tile_v), b = __builtin_amdgcn_readfirstlane(b_v);   // wave-uniform
+    // workgroup = 4 waves side by side in ONE pixel row, NPX consecutive pixels each: blocks walk the frame in raster order, so
+    // the pixels an XCD works on at any time are a band of a few rows whose source footprint (band + disparity halo, all
+    // views) stays inside its 4 MiB L2 (see the launcher)
+    const int NPX = p.npx;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int y = ty;                                     // this wave's pixel row
+    const int yc = min(y, p.h - 1);
+    const int x_base = (tx * 4 + wv) * NPX;
+    const size_t hw = (size_t)p.h * p.w;
+    const int Wp = p.w + 2, Hp = p.h + 2;
+    const int JB = (p.D + DL - 1) / DL;                   // candidate blocks per pixel
+
+    // ---- wave-private LDS ----
+    const int OUT_PX = min(8, NPX);                       // pixels staged before a flush of row segments (NCHW fp32 output only)
+    const int out_bytes = p.cost_hi ? 0 : OUT_PX * DL * 4;
+    const int pv_bytes = p.V * NPX * 32;
+    const int wave_bytes = pv_bytes + (CAP + 1) * 16 + (CAP + 4) * 4 + out_bytes + (LEAD ? VG * 65 * 32 : 0);
+    unsigned char* wbase = smem + wv * wave_bytes;
+    float4*   pvtab = reinterpret_cast<float4*>(wbase);                                         // [V][NPX px][2]
+    float4*   ctab  = reinterpret_cast<float4*>(wbase + pv_bytes);                              // [zero slot | CAP items] x 4 taps
+    uint32_t* items = reinterpret_cast<uint32_t*>(wbase + pv_bytes + (CAP + 1) * 16);           // [CAP + pad] byte offsets
+    float*    outb  = reinterpret_cast<float*>(wbase + pv_bytes + (CAP + 1) * 16 + (CAP + 4) * 4);   // [OUT_PX][DL]
+    float4*   gslot = reinterpret_cast<float4*>(wbase + pv_bytes + (CAP + 1) * 16 + (CAP + 4) * 4 + out_bytes);   // LEAD: [VG][1 + 64 runs][2]
+
+    // ---- depth-linear projection terms for the wave's 16 pixels x V views (once per tile row) ----
+    for (int e = lane; e < NPX * p.V; e += 64) {
+        const int q = e % NPX, v = e / NPX;
+        const int xc = min(x_base + q, p.w - 1);
+        const size_t pix = (size_t)yc * p.w + xc;
+        const float r0 = p.rays[((size_t)b * 3 + 0) * hw + pix];
+        const float r1 = p.rays[((size_t)b * 3 + 1) * hw + pix];
+        const float r2 = p.rays[((size_t)b * 3 + 2) * hw + pix];
+        const PixelView pv = make_pixel_view(p.intM + (size_t)b * 9, p.poses + ((size_t)b * p.V + v) * 16, r0, r1, r2);
+        pvtab[e * 2 + 0] = make_float4(pv.rpx, pv.rpy, pv.rpz, pv.rcz);
+        pvtab[e * 2 + 1] = make_float4(pv.kt0, pv.kt1, pv.kt2, pv.tz);
+    }
+    if (lane == 0) ctab[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    fwave_lds_fence();
+
+    const uint32_t texel_bytes = (uint32_t)p.F * (uint32_t)sizeof(FeatT);
+    const int nchunk = (int)(texel_bytes / 16);
+    const uint32_t xlim = __float_as_uint((float)(p.w + 1)), ylim = __float_as_uint((float)(p.h + 1));   // see cost_volume_fast.hip
+    const float fwc = (float)p.w, fhc = (float)p.h;
+    const int j0 = lane;
+    const int sub = lane & (LPU - 1), tap = (lane / LPU) & 3, upair = lane / (4 * LPU);          // correlation: chunk, tap, item of the pass
+    const uint32_t lane_src_off = (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes + (uint32_t)sub * 16u;
+    const unsigned char* __restrict__ ref_row = reinterpret_cast<const unsigned char*>(p.ref_feat) +
+        ((size_t)b * hw + (size_t)yc * p.w) * texel_bytes;
+    const float invV = 1.0f / (float)p.V;
+    unsigned long long vmask = 0ull;                                              // homography.py:97, read once
+    for (int v = 0; v < p.V; ++v) vmask |= (unsigned long long)(p.is_valid[b * p.V + v] == 1) << v;
+    vmask = __builtin_amdgcn_readfirstlane((uint32_t)vmask) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(vmask >> 32)) << 32);
+    float mu_row, sg_row;                                                         // lane q holds reference pixel q of the row
+    {
+        const size_t pixr = (size_t)yc * p.w + min(x_base + (lane & 15), p.w - 1);      // NPX <= 16
+        mu_row = p.ref_gmm[((size_t)b * 2 + 0) * hw + pixr];
+        sg_row = p.ref_gmm[((size_t)b * 2 + 1) * hw + pixr];
+    }
+    const size_t map_texels = (size_t)Hp * Wp;
+    // source view v of frame b is image v*B + b (view-major, homography.py:105); byte offsets inside the frame's views fit
+    // 32 bits (checked by the launcher)
+    const uint32_t src_vstride = (uint32_t)((size_t)p.B * map_texels * texel_bytes);
+    const size_t sgm_vstride = (size_t)p.B * map_texels * 8;
+    const unsigned char* const src_b = reinterpret_cast<const unsigned char*>(p.src_feat) + (size_t)b * map_texels * texel_bytes;
+    const unsigned char* const sgm_b = reinterpret_cast<const unsigned char*>(p.src_gmm) + (size_t)b * map_texels * 8;
+    const float kappa = p.kappa;
+
+    for (int jb = 0; jb < JB; ++jb) {                                             // candidate block of 64 candidates
+        const int j = jb * DL + j0;
+        const float kj = p.k[min(j, p.D - 1)];
+        for (int q = 0; q < NPX; ++q) {                                           // pixel within the wave's row segment
+            const int x = x_base + q;
+            const bool live = (x < p.w) && (y < p.h) && (j < p.D);
+            // the pixel's reference vector: this lane's chunk(s), kept in registers for all views
+            uint4 rvp[CPL];
+            {
+                const unsigned char* rp = ref_row + (__umul24((uint32_t)min(x, p.w - 1), texel_bytes) + (uint32_t)sub * 16u);
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc)
+                    rvp[cc] = (FULL || (sub + LPU * cc < nchunk)) ? *reinterpret_cast<const uint4*>(rp + cc * CSTR) : make_uint4(0, 0, 0, 0);
+            }
+            float d;
+            {
+                const float mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu_row), q));
+                const float sg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg_row), q));
+                d = __builtin_fmaf(sg, kj, mu);                                   // MAGNET.py:155
+            }
+            d = live ? d : __builtin_nanf("");                                    // dead lane -> out of image below
+            float acc = 0.f;
+
+            // (item, tap) dot products of items [0, n) of the LDS list -> ctab[1 + item]
+            auto correlate = [&](const int n) {
+                for (int ps = 0; ps < n; ps += IPP * NPASS) {
+                    uint4 sv[NPASS][CPL];
+                    uint32_t off[NPASS];
+#pragma unroll
+                    for (int a = 0; a < NPASS; ++a) off[a] = items[min(ps + IPP * a + upair, n)];   // tail: the pad item
+#pragma unroll
+                    for (int a = 0; a < NPASS; ++a) {
+                        if (a > 0 && ps + IPP * a >= n) break;                    // wave-uniform: this pass holds no item
+                        const unsigned char* sp = src_b + (off[a] + lane_src_off);
+#pragma unroll
+                        for (int cc = 0; cc < CPL; ++cc)
+                            sv[a][cc] = (FULL || (sub + LPU * cc < nchunk)) ? *reinterpret_cast<const uint4*>(sp + cc * CSTR) : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int a = 0; a < NPASS; ++a) {
+                        if (a > 0 && ps + IPP * a >= n) break;
+                        float part = 0.f;
+#pragma unroll
+                        for (int cc = 0; cc < CPL; ++cc) part = fdot_chunk(rvp[cc], sv[a][cc], part, FeatT());
+                        part = LPU == 8 ? freduce8(part) : freduce4(part);
+                        const int it = ps + IPP * a + upair;
+                        if (sub == 0 && it < n) reinterpret_cast<float*>(ctab + it + 1)[tap] = part;
+                    }
+                }
+            };
+
+            for (int v0 = 0; v0 < p.V; v0 += VG) {
+                // ---------------- phase A: geometry, (mu,sigma) taps, gate, distinct open quads — VG independent chains ----------------
+                float wnw[VG], wne[VG], wsw[VG], wse[VG];
+                uint32_t qoff[VG];                                                // byte offset of the quad's first texel in the frame's views
+                int incl[VG], cnt[VG];
+                bool gate[VG], fresh[VG];
+                float zw[VG];
+                uint32_t qi[VG];
+                bool inwin[VG];
+                float4 g0[VG], g1[VG];
+                {
+                    // A1: the VG projection-table reads, then A2: geometry and the (mu,sigma) tap loads of all VG views — issued
+                    // unconditionally (quad origin clamped into the padded map, so out-of-window lanes read valid memory) so that
+                    // the compiler does not wrap each view's loads into an exec-masked region with its own vmcnt(0)
+                    float4 pa[VG], pb[VG];
+#pragma unroll
+                    for (int u = 0; u < VG; ++u) {
+                        const int vv = min(v0 + u, p.V - 1);                      // tail group: clamped view, masked below
+                        pa[u] = pvtab[(vv * NPX + q) * 2 + 0]; pb[u] = pvtab[(vv * NPX + q) * 2 + 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < VG; ++u) {
+                        const int vv = min(v0 + u, p.V - 1);
+                        const float Px = __builtin_fmaf(pa[u].x, d, pb[u].x);     // homography.py:132
+                        const float Py = __builtin_fmaf(pa[u].y, d, pb[u].y);
+                        const float Pz = __builtin_fmaf(pa[u].z, d, pb[u].z);
+                        zw[u] = __builtin_fmaf(pa[u].w, d, pb[u].w);              // homography.py:137-138
+                        const float rz = __builtin_amdgcn_rcpf(Pz);               // homography.py:133
+                        const float ixs = __builtin_fmaf(Px, rz, 0.5f);           // = (u - 0.5) + 1: padded-map texel coordinate
+                        const float iys = __builtin_fmaf(Py, rz, 0.5f);
+                        const float x0f = __builtin_floorf(ixs), y0f = __builtin_floorf(iys);
+                        const float bx = ixs - x0f, by = iys - y0f;
+                        const float ax = 1.0f - bx, ay = 1.0f - by;
+                        wnw[u] = ax * ay; wne[u] = bx * ay; wsw[u] = ax * by; wse[u] = bx * by;   // homography.py:150-152
+                        inwin[u] = (__float_as_uint(ixs) < xlim) && (__float_as_uint(iys) < ylim);
+                        const int xq = (int)__builtin_amdgcn_fmed3f(x0f, 0.0f, fwc), yq = (int)__builtin_amdgcn_fmed3f(y0f, 0.0f, fhc);
+                        qi[u] = (uint32_t)__mul24(yq, Wp) + (uint32_t)xq;        // quad origin in the padded map (exact when inwin)
+                        const unsigned char* __restrict__ sgm = sgm_b + (size_t)vv * sgm_vstride;
+                        if (!LEAD) {
+                            g0[u] = *reinterpret_cast<const float4*>(sgm + qi[u] * 8u);             // (mu,sg) x0, x0+1 of row y0
+                            g1[u] = *reinterpret_cast<const float4*>(sgm + (qi[u] + (uint32_t)Wp) * 8u);
+                        }
+                    }
+                    if (LEAD) {
+                        // candidates are sorted along the epipolar segment: lanes on the same quad form runs; the first lane of a
+                        // run loads the 2 x 16 bytes (64 -> ~7 L1 accesses per load), the run shares them through an LDS slot
+                        int run[VG];
+#pragma unroll
+                        for (int u = 0; u < VG; ++u) {
+                            const int vv = min(v0 + u, p.V - 1);
+                            const unsigned char* __restrict__ sgm = sgm_b + (size_t)vv * sgm_vstride;
+                            const uint32_t tkey = inwin[u] ? qi[u] : FKEY_CLOSED;
+                            const uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);
+                            const bool lead = inwin[u] && (tkey != tprev);
+                            const unsigned long long lbal = __ballot(lead);
+                            run[u] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lbal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lbal, lead ? 1u : 0u));
+                            if (lead) {
+                                gslot[(u * 65 + run[u]) * 2 + 0] = *reinterpret_cast<const float4*>(sgm + qi[u] * 8u);
+                                gslot[(u * 65 + run[u]) * 2 + 1] = *reinterpret_cast<const float4*>(sgm + (qi[u] + (uint32_t)Wp) * 8u);
+                            }
+                        }
+                        fwave_lds_fence();
+#pragma unroll
+                        for (int u = 0; u < VG; ++u) { g0[u] = gslot[(u * 65 + run[u]) * 2 + 0]; g1[u] = gslot[(u * 65 + run[u]) * 2 + 1]; }
+                        fwave_lds_fence();
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < VG; ++u) {
+                    // A3: consistency gate, distinct open quads
+                    const int vv = min(v0 + u, p.V - 1);
+                    const bool vok = (v0 + u < p.V) && ((vmask >> vv) & 1ull);    // homography.py:97 (wave-uniform)
+                    float mu_w = g0[u].x * wnw[u], sg_w = g0[u].y * wnw[u];
+                    mu_w = __builtin_fmaf(g0[u].z, wne[u], mu_w); sg_w = __builtin_fmaf(g0[u].w, wne[u], sg_w);
+                    mu_w = __builtin_fmaf(g1[u].x, wsw[u], mu_w); sg_w = __builtin_fmaf(g1[u].y, wsw[u], sg_w);
+                    mu_w = __builtin_fmaf(g1[u].z, wse[u], mu_w); sg_w = __builtin_fmaf(g1[u].w, wse[u], sg_w);
+                    gate[u] = vok & inwin[u] & (__builtin_fabsf(zw[u] - mu_w) < sg_w * kappa);     // homography.py:157-158
+                    if (GBITS && live && vok)
+                        p.gate_bits[(((size_t)b * p.V + vv) * p.D + j) * hw + (size_t)y * p.w + x] = gate[u] ? 1 : 0;
+                    qoff[u] = (uint32_t)vv * src_vstride + __umul24(qi[u], texel_bytes);
+                    const uint32_t key = gate[u] ? qi[u] : FKEY_CLOSED;
+                    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)key, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                    fresh[u] = gate[u] && (key != prev);
+                    const unsigned long long bal = __ballot(fresh[u]);
+                    cnt[u] = __popcll(bal);
+                    incl[u] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                   __builtin_amdgcn_mbcnt_lo((uint32_t)bal, fresh[u] ? 1u : 0u));  // view's items at or below this lane
+                }
+                int n_tot = 0;
+#pragma unroll
+                for (int u = 0; u < VG; ++u) n_tot += cnt[u];
+                if (n_tot == 0) continue;                                         // wave-uniform: nothing open in this group
+                if (n_tot <= CAP) {
+                    // ---------------- phase B: one item list for the group ----------------
+                    int base = 0;
+#pragma unroll
+                    for (int u = 0; u < VG; ++u) {
+                        if (fresh[u]) items[base + incl[u] - 1] = qoff[u];
+                        incl[u] = gate[u] ? base + incl[u] : 0;                   // -> slot of this lane's item (0 = the zero slot)
+                        base += cnt[u];
+                    }
+                    if (lane == 0) items[n_tot] = 0u;                             // pad item: view 0, texel 0
+                    fwave_lds_fence();
+                    correlate(n_tot);
+                    fwave_lds_fence();
+                    // ---------------- phase C: bilinear combine + view accumulation ----------------
+#pragma unroll
+                    for (int u = 0; u < VG; ++u) {
+                        const float4 c4 = ctab[incl[u]];
+                        float c = c4.x * wnw[u];
+                        c = __builtin_fmaf(c4.y, wne[u], c);
+                        c = __builtin_fmaf(c4.z, wsw[u], c);
+                        c = __builtin_fmaf(c4.w, wse[u], c);
+                        acc += gate[u] ? c : 0.f;                                 // homography.py:159,116 (fp32 here)
+                    }
+                    fwave_lds_fence();                                            // ctab/items are rewritten by the next group
+                } else {
+                    // more distinct open quads than the tables hold (long epipolar segments): one view at a time
+#pragma unroll
+                    for (int u = 0; u < VG; ++u) {
+                        if (cnt[u] == 0) continue;                                // wave-uniform
+                        if (fresh[u]) items[incl[u] - 1] = qoff[u];
+                        if (lane == 0) items[cnt[u]] = 0u;
+                        fwave_lds_fence();
+                        correlate(cnt[u]);
+                        fwave_lds_fence();
+                        const float4 c4 = ctab[gate[u] ? incl[u] : 0];
+                        float c = c4.x * wnw[u];
+                        c = __builtin_fmaf(c4.y, wne[u], c);
+                        c = __builtin_fmaf(c4.z, wsw[u], c);
+                        c = __builtin_fmaf(c4.w, wse[u], c);
+                        acc += gate[u] ? c : 0.f;
+                        fwave_lds_fence();
+                    }
+                }
+            }
+            const float cval = acc * invV;                                        // homography.py:118,120
+            if (p.cost_hi) {
+                // split-bf16 channel-last output for the conv kernel: lanes = consecutive channels of one row
+                if (live) {
+                    const uint16_t hi = f32_to_bf16_rne(cval);
+                    const uint16_t lo = f32_to_bf16_rne(cval - bf16_to_f32(hi));
+                    const size_t e = (((size_t)b * Hp + (y + 1)) * Wp + (x + 1)) * (size_t)p.cost_ld + j;
+                    p.cost_hi[e] = hi; p.cost_lo[e] = lo;
+                }
+                continue;
+            }
+            outb[(q & (OUT_PX - 1)) * DL + j0] = cval;                            // OUT_PX and NPX are powers of two
+            if (((q + 1) & (OUT_PX - 1)) == 0) {
+                // ---- OUT_PX px x 64 results: LDS -> coalesced row segments of cost[b, j, y, :] ----
+                const int q_base = q + 1 - OUT_PX;
+                fwave_lds_fence();
+                if (y < p.h) {
+                    for (int e = lane; e < OUT_PX * DL; e += 64) {
+                        const int qq = e & (OUT_PX - 1), jj = e / OUT_PX;
+                        const int jo = jb * DL + jj, xo = x_base + q_base + qq;
+                        if (jo < p.D && xo < p.w)
+                            p.cost[(size_t)b * p.cost_bstride + (size_t)jo * hw + (size_t)y * p.w + xo] = outb[qq * DL + jj];
+                    }
+                }
+                fwave_lds_fence();
+            }
+        }
+    }
+}
+
+static size_t fast64_lds_bytes(const CvParams& p, int lead_vg = 0) {
+    return (size_t)4 * (p.V * p.npx * 32 + 65 * 16 + 68 * 4 + (p.cost_hi ? 0 : (p.npx < 8 ? p.npx : 8) * 64 * 4) + lead_vg * 65 * 32);
+}
+
+template <typename FeatT, int CPL, bool FULL, int MINW, int LPU, int VG>
+static hipError_t launch_fast64_v(const CvParams& p0, hipStream_t stream) {
+    // Pixels per wave.  A wave owns its pixels for NPX x V iterations, and everything the resident waves of an XCD
+    // (~900) own at one time must keep its source footprint in that XCD's 4 MiB L2, or texels shared by neighbouring pixels
+    // are fetched from HBM again and again (measured with 16 x 4 tiles: 2.3-3 GB per launch for 0.85 GB of inputs).
+    // Footprint ~ (900 * NPX / w + 2 * halo) rows x (w + 2) x V x texel bytes.  Measured at C2 (profiles/r2): NPX = 8 in raster
+    // order cuts the L2 misses 2.6x (FETCH 2.1 -> 0.83 GB per launch = the compulsory bytes); smaller NPX pays more per-wave
+    // prologue (projection table, validity mask) than it saves.
+    CvParams p = p0;
+    p.npx = 8;
+    if (p.ablate & 0x40) p.npx = 1 << ((p.ablate >> 3) & 7) > 16 ? 16 : 1 << ((p.ablate >> 3) & 7);   // dev: path bits 11..13 = log2(NPX)
+    p.tiles_x = (p.w + 4 * p.npx - 1) / (4 * p.npx);
+    p.tiles_y = p.h;
+    const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
+    if constexpr (sizeof(FeatT) == 2 && FULL) {
+        if (p.ablate & 0x80) {                                                    // dev (path bit 15): leader (mu,sigma) loads through LDS
+            hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 2>), grid, block, fast64_lds_bytes(p, VG), stream, p);
+            return hipGetLastError();
+        }
+    }
+    if (p.gate_bits) hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 1>), grid, block, fast64_lds_bytes(p), stream, p);
+    else hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 0>), grid, block, fast64_lds_bytes(p), stream, p);
+    return hipGetLastError();
+}
+
+template <typename FeatT, int CPL, bool FULL, int MINW, int LPU>
+static hipError_t launch_fast64(const CvParams& p, hipStream_t stream) {
+    // views per group: as many as possible (<= 4) without idle slots in the last group
+    int vg = p.V >= 4 ? 4 : p.V;
+    if (p.V > 4 && p.V % 4 != 0 && (p.V % 3 == 0 || p.V % 4 < p.V % 3)) vg = 3;
+    if (p.ablate & 0x40) vg = 1 + ((p.ablate >> 1) & 3);                          // dev: path bits 9..10 choose VG - 1 when bit 14 is set
+    switch (vg) {
+        case 1: return launch_fast64_v<FeatT, CPL, FULL, MINW, LPU, 1>(p, stream);
+        case 2: return launch_fast64_v<FeatT, CPL, FULL, MINW, LPU, 2>(p, stream);
+        case 3: return launch_fast64_v<FeatT, CPL, FULL, MINW, LPU, 3>(p, stream);
+        default: return launch_fast64_v<FeatT, CPL, FULL, MINW, LPU, 4>(p, stream);
+    }
+}
+
+// D > 32 with candidates sampled in the kernel; called by launch_cv_fast, which has checked everything else.
+hipError_t launch_cv_fast64(const CvParams& p, hipStream_t stream, bool* handled) {
+    *handled = false;
+    const size_t esz = p.feat_bf16 ? 2 : 4;
+    if (p.D <= 32) return hipSuccess;
+    if ((size_t)p.V * p.B * (size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets over all views
+    if ((size_t)p.V * 512 * 4 > 48 * 1024) return hipSuccess;
+    const int nchunk = (int)(p.F * esz / 16);
+    *handled = true;
+    if (p.feat_bf16) {
+        if (nchunk == 8)  return launch_fast64<uint16_t, 2, true, 5, 4>(p, stream);       // F = 64: 4 lanes x 32 B per (item, tap) unit
+        if (nchunk <= 8)  return launch_fast64<uint16_t, 1, false, 5, 8>(p, stream);
+        if (nchunk <= 16) return launch_fast64<uint16_t, 2, false, 5, 8>(p, stream);
+    } else {
+        if (nchunk == 16) return launch_fast64<float, 2, true, 5, 8>(p, stream);          // F = 64
+        if (nchunk <= 8)  return launch_fast64<float, 1, false, 5, 8>(p, stream);
+        if (nchunk <= 16) return launch_fast64<float, 2, false, 5, 8>(p, stream);
+        if (nchunk <= 32) return launch_fast64<float, 4, false, 4, 8>(p, stream);
+    }
+    *handled = false;
+    return hipSuccess;
+}
+
+}  // namespace magnet

@@ -34,6 +34,7 @@ struct CvParams {
     uint16_t*      cost_lo;
     long long      cost_ld;
     uint8_t*       gate_bits;         // optional debug output (B,V,D,h,w)
+    int            npx;               // cost_volume_fast64.hip: pixels per wave (set by its launcher)
     float k[MAGNET_MAX_CANDIDATES];   // (float)k_j, read with wave-uniform indices (scalar loads)
 };
 
@@ -67,6 +68,7 @@ hipError_t launch_cv_generic(const CvParams& p, hipStream_t stream);
 hipError_t launch_cv_worklist(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cv_cand(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled);
+hipError_t launch_cv_fast64(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cvf_bwd(const CvParams& p, const float* gout, float* grad_ref, float* grad_src, hipStream_t stream,
                           bool* handled);
 

@@ -58,12 +58,20 @@ WORKLIST_RTOL = 2e-5
 GATE_FLIP_FRAC = 1e-5     # SURVEY.md §7 / VERDICT r1: allowed fraction of flipped consistency gates (production matcher)
 
 
-def assert_tolerant_parity(hip, orc, hip_gates=None, orc_gates=None, n_views=4, label=""):
+def assert_tolerant_parity(hip, orc, hip_gates=None, orc_gates=None, n_views=4, label="", sens=None, eps=0.0):
     """Production matcher (path 0/4).  With gate bits from both sides (B,V,D,h,w): the gate-flip fraction is <= 1e-5 (at
     least one flip is tolerated on tiny inputs) and every value outside the tolerance sits on an entry with a flipped gate.
-    Without gate bits: the fraction of out-of-tolerance entries is <= n_views * 1e-5."""
-    st = cost_stats(hip, orc, WORKLIST_ATOL, WORKLIST_RTOL)
+    Without gate bits: the fraction of out-of-tolerance entries is <= n_views * 1e-5.
+    Value tolerance: 2e-5 + 2e-5 |oracle| + eps * sens, where sens = position_sensitivity() (the score's slope in the
+    sample position) and eps = pos_eps(h, w) texels — see the comment above position_sensitivity()."""
     hipn = hip.detach().cpu().numpy() if isinstance(hip, torch.Tensor) else np.asarray(hip)
+    slack = eps * sens if sens is not None else 0.0
+    diff0 = np.abs(hipn.astype(np.float64) - orc.astype(np.float64))
+    bad0 = diff0 > (WORKLIST_ATOL + WORKLIST_RTOL * np.abs(orc) + slack)
+    st = dict(frac_bitwise=float(np.mean(hipn == orc)), frac_flip=float(bad0.mean()),
+              max_abs_nonflip=float(diff0[~bad0].max()) if (~bad0).any() else 0.0, max_abs=float(diff0.max()),
+              n=int(diff0.size), finite=bool(np.isfinite(hipn).all()),
+              frac_over_2e5=float(np.mean(diff0 > WORKLIST_ATOL + WORKLIST_RTOL * np.abs(orc))))
     assert st["finite"] or not np.isfinite(orc).all(), f"{label}: non-finite values in the HIP cost volume"
     if hip_gates is not None:
         hg = hip_gates.detach().cpu().numpy() if isinstance(hip_gates, torch.Tensor) else np.asarray(hip_gates)
@@ -72,9 +80,7 @@ def assert_tolerant_parity(hip, orc, hip_gates=None, orc_gates=None, n_views=4, 
         st["gate_flips"], st["gates"], st["gate_flip_frac"] = n_flip, n_gate, n_flip / n_gate
         print(f"[parity {label} production] {st}")
         assert n_flip <= max(1, int(GATE_FLIP_FRAC * n_gate)), f"{label}: {st}"
-        diff = np.abs(hipn.astype(np.float64) - orc.astype(np.float64))
-        bad = diff > (WORKLIST_ATOL + WORKLIST_RTOL * np.abs(orc))
-        unexplained = bad & ~flipped.any(axis=1)
+        unexplained = bad0 & ~flipped.any(axis=1)
         assert not unexplained.any(), f"{label}: {int(unexplained.sum())} entries differ without a flipped gate: {st}"
     else:
         print(f"[parity {label} production] {st}")
@@ -95,3 +101,59 @@ def assert_cost_parity(hip, orc, path=0, flip_frac=0.0, label="", n_views=4):
     assert st["finite"], f"{label}: non-finite values in the HIP cost volume"
     assert st["frac_flip"] <= flip_frac, f"{label}: {st}"
     return st
+
+
+# ---- position-aware value tolerance of the production matcher -------------------------------------------------------
+# The production kernel computes the sample position with a different (shorter) rounding sequence than the reference, so
+# its texel coordinates differ from the oracle's by a few ulp of the image width.  The score is bilinear in the position
+# inside a quad, so such a shift changes an entry by  delta_pos * (|dc/dx| + |dc/dy|)  — for white-noise features (the
+# synthetic inputs of SURVEY.md §8d: adjacent texels are independent) that slope is O(10), i.e. a 3e-5 px shift moves the
+# score by ~3e-4 although neither side is "wrong".  position_sensitivity() evaluates that slope exactly (fp64 geometry,
+# fp64 tap dot products, torch, on the GPU when there is one) so the value tolerance can stay at 2e-5 everywhere else.
+def pos_eps(h, w):
+    """Allowed position difference in texels: 4 ulp of the padded image extent (reference round trip: ~2 ulp, measured
+    1.5e-5 px at w = 160; production kernel: v_rcp_f32 1 ulp + one fused rounding)."""
+    return 4.0 * float(np.spacing(np.float32(max(h, w) + 1)))
+
+
+def position_sensitivity(inp, k_list, gates, device=None):
+    """sum_v gate[b,v,j,p] * (|dc/dx| + |dc/dy|) / V  for every cost entry, shape (B,D,h,w), float64 numpy.
+    inp: the CPU input dict (features already bf16-rounded if the kernel stores bf16); gates: oracle gate bits (B,V,D,h,w)."""
+    dev = device or torch.device("cpu")
+    f64 = torch.float64
+    ref = inp["ref_feat"].to(dev, f64); src = inp["nghbr_feat"].to(dev, f64)
+    B, F, h, w = ref.shape
+    V = src.shape[0] // B
+    D = len(k_list)
+    K = inp["cam_intrins"]["intM"].to(dev, f64); rays = inp["cam_intrins"]["unit_ray_array_2D"].to(dev, f64)
+    T = inp["nghbr_poses"].to(dev, f64)
+    mu = inp["ref_gmms"][:, 0].reshape(B, 1, h * w).to(dev, f64); sg = inp["ref_gmms"][:, 1].reshape(B, 1, h * w).to(dev, f64)
+    kk = torch.tensor([float(np.float32(x)) for x in k_list], dtype=f64, device=dev).reshape(1, D, 1)
+    d = mu + sg * kk                                                             # (B,D,hw)
+    g = torch.as_tensor(np.asarray(gates), device=dev).reshape(B, V, D, h * w).to(f64)
+    out = torch.zeros(B, D, h * w, dtype=f64, device=dev)
+    srcp = torch.nn.functional.pad(src, (1, 2, 1, 2))                            # zero border (one extra for the +1 taps)
+    for b in range(B):
+        rf = ref[b].reshape(F, h * w)                                            # (F,hw)
+        for v in range(V):
+            if int(inp["is_valid"][b, v]) != 1:
+                continue
+            R, t = T[b, v, :3, :3], T[b, v, :3, 3]
+            rp = (K[b] @ R) @ rays[b]; tp = K[b] @ t                             # (3,hw), (3,)
+            P = tp.reshape(3, 1, 1) + rp.reshape(3, 1, h * w) * d[b].reshape(1, D, h * w)
+            ix = P[0] / P[2] - 0.5; iy = P[1] / P[2] - 0.5                       # texel coordinates (D,hw)
+            ok = torch.isfinite(ix) & torch.isfinite(iy) & (ix >= -1) & (ix < w) & (iy >= -1) & (iy < h)
+            x0 = torch.where(ok, torch.floor(ix), torch.zeros_like(ix)); y0 = torch.where(ok, torch.floor(iy), torch.zeros_like(iy))
+            fx = torch.where(ok, ix - x0, torch.zeros_like(ix)); fy = torch.where(ok, iy - y0, torch.zeros_like(iy))
+            xi = (x0 + 1).long(); yi = (y0 + 1).long()                           # padded coordinates
+            sp = srcp[v * B + b]                                                 # (F,h+3,w+3)
+            acc = torch.zeros(D, h * w, dtype=f64, device=dev)
+            for j0 in range(0, D, 8):                                            # bounded memory: 8 candidates at a time
+                sl = slice(j0, min(D, j0 + 8))
+                yy, xx = yi[sl], xi[sl]
+                c = [torch.einsum("fn,fjn->jn", rf, sp[:, yy + dy, xx + dx]) for dy in (0, 1) for dx in (0, 1)]   # c00 c01 c10 c11
+                dcx = (c[1] - c[0]).abs() * (1 - fy[sl]) + (c[3] - c[2]).abs() * fy[sl]
+                dcy = (c[2] - c[0]).abs() * (1 - fx[sl]) + (c[3] - c[1]).abs() * fx[sl]
+                acc[sl] = (dcx + dcy) * ok[sl]
+            out[b] += acc * g[b, v]
+    return (out / V).reshape(B, D, h, w).cpu().numpy()

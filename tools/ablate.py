@@ -19,8 +19,9 @@ out = torch.empty(B, wl.D, wl.h, wl.w, device=dev)
 ld = (wl.D + 7) // 8 * 8 + 256
 hi = torch.zeros(B * (wl.h + 2) * (wl.w + 2), ld, dtype=torch.bfloat16, device=dev); lo = torch.zeros_like(hi)
 fdt = wl.feat_dtype
-VARIANTS = (("production (auto)", 0), ("production, VALU correlation", 0x104), ("exact cand", 2), ("exact cand noP2", 0x102),
-            ("exact cand geom only", 0x802), ("exact worklist", 3))
+def _dev(vg, lnpx): return 4 | 0x4000 | ((vg - 1) << 9) | (lnpx << 11)
+VARIANTS = [("production (auto)", 0), ("batched VG=1 NPX=8", _dev(1, 3)), ("batched VG=2 NPX=8", _dev(2, 3)), ("batched VG=4 NPX=8", _dev(4, 3)),
+            ("batched VG=4 NPX=16", _dev(4, 4)), ("per-view kernel (16x4 tiles)", 0x8004), ("exact cand", 2)]
 for name, path in VARIANTS:
     if split and (path & 0xff) == 3:
         continue
