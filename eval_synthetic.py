@@ -81,7 +81,7 @@ def main():
                     help="folder layout; the split file has '<scene> <frame>' or '<scene> <sequence> <frame>' lines")
     ap.add_argument("--psmnet", action="store_true", help="use the PSMNet F-Net (matrix-core path) instead of the stub F-Net")
     a = ap.parse_args()
-    from tests.stubs import StubDNet, StubFNet, make_args, seeded_magnet_weights
+    from magnet_amd.standin import StubDNet, StubFNet, make_args, seeded_magnet_weights
     if not torch.cuda.is_available():
         raise SystemExit("eval_synthetic.py needs an MI355X (no CPU fallback)")
     device = torch.device("cuda:0")

@@ -2,11 +2,15 @@
 `forward(ref_img, nghbr_imgs, nghbr_poses, is_valid, cam_intrins, mode)` signature, return value
 (list of (B,2,H,W) tensors) and state_dict keys (`g_net.gnet.*`, `mask_head.*`, `d_net.*`, `f_net.*`).
 
-What runs where:
-  * candidate sampling + warping + consistency-weighted score  -> HIP kernel (lib.cost_volume_cw)
-  * G-Net / mask-head convolutions                              -> torch (MIOpen) — SURVEY.md §8 N1 is next
-  * Gaussian update tail, convex upsampling                     -> HIP kernels (lib.gaussian_update/upsample_depth)
-  * D-Net / F-Net                                               -> caller-provided modules (out of scope, §2 #5-6)
+What runs where (inference, conv_backend='mfma'):
+  * candidate sampling + warping + consistency-weighted score  -> HIP kernel (lib.cost_volume_cw, production matcher)
+  * G-Net / mask-head convolutions                              -> HIP matrix-core kernel (lib.conv_mfma, bf16x3 split)
+  * Gaussian update tail, convex upsampling                     -> HIP kernels (lib.gaussian_update*/upsample_depth*)
+  * a PSMNet-structured F-Net                                   -> HIP matrix-core path (magnet_amd/fnet.py)
+  * D-Net                                                       -> caller-provided module (out of scope)
+Under autograd (mode='train' with trainable g_net / mask_head) the convolutions, the Gaussian update and the convex
+upsampling are torch ops, so gradients reach g_net and mask_head exactly as in the reference (train_MaGNet.py:87-98);
+the matcher is forward-only there too (the reference detaches its inputs, MAGNET.py:154,167-168).
 """
 from __future__ import annotations
 
@@ -30,8 +34,22 @@ def depth_sampling(sampling_range, n_samples) -> list:
     return [(k[i + 1] + k[i]) / 2 for i in range(n_samples)]
 
 
+def _upsample_depth_torch(depth, up_mask, k):
+    """Differentiable form of the learned convex upsampling (reference models/MAGNET.py:15-27): per low-resolution
+    pixel, softmax over the 9 neighbours of each of the k*k sub-pixels, convex combination of the zero-padded 3x3 patch."""
+    N, C, H, W = depth.shape
+    wgt = torch.softmax(up_mask.reshape(N, 1, 9, k, k, H, W), dim=2)
+    patch = nn.functional.unfold(depth, kernel_size=3, padding=1).reshape(N, C, 9, 1, 1, H, W)
+    up = (wgt * patch).sum(dim=2)                                          # (N, C, k, k, H, W)
+    return up.permute(0, 1, 4, 2, 5, 3).reshape(N, C, k * H, k * W)
+
+
 def upsample_depth_via_mask(depth, up_mask, k):
-    """Learned convex upsampling (reference models/MAGNET.py:15-27) on the HIP kernel."""
+    """Learned convex upsampling (reference models/MAGNET.py:15-27).  HIP kernel when no gradient is needed; under
+    autograd (MagnetLoss is computed on these tensors, train_MaGNet.py:87-98) the torch form, so that g_net and
+    mask_head receive their gradients."""
+    if torch.is_grad_enabled() and (depth.requires_grad or up_mask.requires_grad):
+        return _upsample_depth_torch(depth, up_mask, int(k))
     return lib.upsample_depth(depth.detach().float().contiguous(), up_mask.detach().float().contiguous(), int(k))
 
 
@@ -226,6 +244,9 @@ class MAGNET(nn.Module):
         # convolution over the D cost channels only (K = 9*(256+D) -> 9*round_up(D,32) per iteration).
         partial = None
         if n_iter >= 2 and self.hoist_invariant:
+            # the invariant convolution runs over ALL channels of the cached buffer with the cost-channel weights zeroed: clear
+            # what the previous forward left there, or one frame with a non-finite cost (0 * NaN) would poison every later call
+            gin_hi[:, :Dp].zero_(); gin_lo[:, :Dp].zero_()
             main.wait_event(ev_pack)
             partial = g_stack.run_invariant(gin_hi, gin_lo, ctot, rows, wp, work, Dp)
         for _ in range(n_iter):

@@ -20,6 +20,13 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_r2():
+    """Round-2 golden vectors from the imported reference (tests/golden/make_golden_r2.py): est_costvolume_CW at the
+    C2 / C4 / C5 shapes, and one training step (loss + gradients)."""
+    return np.load(os.path.join(REPO, "tests", "golden", "golden_r2.npz"))
+
+
+@pytest.fixture(scope="session")
 def hip_lib():
     """Build (if stale) and load libmagnet_hip.so."""
     from magnet_amd import build, lib

@@ -7,60 +7,7 @@ import torch
 import torch.nn as nn
 
 
-class StubDNet(nn.Module):
-    """img (N,3,H,W) -> ((N,2,H/4,W/4) [mu, sigma>0], (N,256,H/4,W/4)) like DNET(dnet=False)
-    (reference: models/DNET.py:62-67, submodules/D_dense_depth.py:187-195)."""
-
-    def __init__(self, seed=0):
-        super().__init__()
-        g = torch.Generator().manual_seed(seed)
-        self.head = nn.Conv2d(3, 2, 4, stride=4)
-        self.feat = nn.Conv2d(3, 256, 4, stride=4)
-        with torch.no_grad():
-            for p in self.parameters():
-                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
-
-    def forward(self, img):
-        o = self.head(img)
-        mu = 1.0 + 3.0 * torch.sigmoid(o[:, 0:1])
-        sigma = 0.05 + 0.3 * torch.sigmoid(o[:, 1:2])
-        return torch.cat([mu, sigma], dim=1), self.feat(img)
-
-
-class StubFNet(nn.Module):
-    """img (N,3,H,W) -> (N,fdim,H/4,W/4) linear signed features like FNET (models/FNET.py:19-20)."""
-
-    def __init__(self, seed=0, fdim=64):
-        super().__init__()
-        g = torch.Generator().manual_seed(seed)
-        self.conv = nn.Conv2d(3, fdim, 4, stride=4)
-        with torch.no_grad():
-            for p in self.parameters():
-                p.copy_(torch.randn(p.shape, generator=g) * 0.7)
-
-    def forward(self, img):
-        return self.conv(img)
-
-
-def make_args(D=5, iters=3, dpv_h=120, dpv_w=160, beta=3, weighting="CW5", fdim=64, V=4):
-    """The argparse fields MAGNET.__init__ reads (reference: models/MAGNET.py:95-104,
-    test_MaGNet.py:89-147)."""
-    return SimpleNamespace(
-        MAGNET_sampling_range=beta, MAGNET_num_samples=D, MAGNET_mvs_weighting=weighting,
-        MAGNET_num_train_iter=iters, MAGNET_num_test_iter=iters, MAGNET_num_source_views=V,
-        dpv_height=dpv_h, dpv_width=dpv_w, downsample_ratio=4, FNET_feature_dim=fdim,
-        DNET_ckpt=None, FNET_ckpt=None, MAGNET_ckpt=None)
-
-
-def seeded_magnet_weights(model, seed=0):
-    """Deterministic g_net / mask_head weights (same draw order for the reference module and ours:
-    both expose `g_net.gnet.{0,2,4,6}` and `mask_head.{0,2,4,6}`)."""
-    g = torch.Generator().manual_seed(seed)
-    with torch.no_grad():
-        for mod in (model.g_net, model.mask_head):
-            for name, p in sorted(mod.state_dict().items()):
-                scale = 0.05 if p.dim() > 1 else 0.01
-                p.copy_(torch.randn(p.shape, generator=g) * scale)
+from magnet_amd.standin import StubDNet, StubFNet, make_args, seeded_magnet_weights  # noqa: F401  (shared with the drivers)
 
 
 def seeded_fnet_state(module, seed=0):
@@ -100,3 +47,34 @@ def procedural_images(N, H, W):
         for c in range(3):
             img[n, c] = np.sin(0.05 * x * (c + 1) + 0.3 * n) * np.cos(0.07 * y + 0.5 * c) + 0.1 * ((x * y + 3 * n) % 7) - 0.3
     return torch.from_numpy(img.astype(np.float32))
+
+
+def train_case():
+    """Inputs of the training-step golden vector G11 (tests/golden/make_golden_r2.py): the G6 stub configuration plus a
+    seeded ground-truth depth map and validity mask at full resolution."""
+    from magnet_amd import synth
+    args = make_args(D=5, iters=3, dpv_h=12, dpv_w=16)
+    gen = torch.Generator().manual_seed(41)
+    B, V = 2, 3
+    ref_img = torch.rand(B, 3, 48, 64, generator=gen)
+    nghbr_imgs = torch.rand(V * B, 3, 48, 64, generator=gen)
+    poses = synth.make_poses("scannet", B, V, gen)
+    valid = torch.ones(B, V, dtype=torch.int32); valid[1, 2] = 0
+    intr = synth.make_intrinsics("scannet", 12, 16, B)
+    gt = torch.rand(B, 1, 48, 64, generator=gen) * 3.0 + 1.0
+    gt_mask = torch.rand(B, 1, 48, 64, generator=gen) > 0.2
+    return args, ref_img, nghbr_imgs, poses, valid, intr, gt, gt_mask
+
+
+def magnet_nll_loss(pred_list, gt_depth, gt_mask, gamma=0.8):
+    """The reference's training loss for MaGNet (utils/losses.py:28-52, 'gaussian'): gamma-weighted mean NLL of every
+    iteration's (mu, sigma) against the ground truth at the valid pixels.  Test-side restatement (losses are outside the
+    product's scope); pinned by G11_loss."""
+    gt = gt_depth[gt_mask]
+    n = len(pred_list)
+    loss = 0.0
+    for i, pred in enumerate(pred_list):
+        mu, sigma = pred[:, 0:1][gt_mask], pred[:, 1:2][gt_mask]
+        var = torch.clamp(sigma * sigma, min=1e-10)
+        loss = loss + gamma ** (n - i - 1) * torch.mean((mu - gt) ** 2 / (2 * var) + 0.5 * torch.log(var))
+    return loss

@@ -1,0 +1,41 @@
+"""bench.py --gpus N starts N ranks by itself (no torchrun): run the launcher at world size 2 on CPU (gloo, --dry-run: no
+kernels) and parse the one JSON line rank 0 prints."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_two_ranks_dry_run():
+    d = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--frames", "5"])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["frames_per_step_all_ranks"] == 10                 # 5 frames per rank, every frame owned once
+    assert d["weight_broadcast_bytes"] == (9 * (256 + 64) * 128 + 128 + 2 * (128 * 128 + 128) + 2 * 128 + 2) * 4   # G-Net at D=64
+
+
+def test_bench_single_rank_dry_run_needs_no_group():
+    d = _run(["--gpus", "1", "--dry-run", "--steps", "2"])
+    assert d["n_gpus"] == 1 and d["weight_broadcast_bytes"] == 0
+
+
+def test_bench_under_torchrun_env_does_not_respawn():
+    """With RANK in the environment (how the driver launches N > 1) bench.py must join the group, not spawn again."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    d = _run(["--gpus", "1", "--dry-run", "--steps", "2"],
+             env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+    assert d["n_gpus"] == 1

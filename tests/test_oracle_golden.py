@@ -154,3 +154,26 @@ def test_G9_costvolume_F_gradients(golden):
     # invalid view (frame 0, view 2) receives exactly zero gradient
     B = golden["G9_ref_feat"].shape[0]
     assert not gs[2 * B + 0].any() and not golden["G9_grad_src"][2 * B + 0].any()
+
+
+BASELINE_GOLDEN = (("C2", 0, True), ("C4", 0, False), ("C5", 2, False))      # name, seed, features rounded to bf16
+
+
+def baseline_golden_inputs(name, seed, bf16):
+    wl = synth.WORKLOADS[name]
+    return wl, synth.make_inputs(wl, B=1, seed=seed, round_bf16=bf16)
+
+
+@pytest.mark.parametrize("name,seed,bf16", BASELINE_GOLDEN)
+def test_G2_baseline_shapes_bitwise(golden_r2, name, seed, bf16):
+    """The reference's est_costvolume_CW output at the full C2 (bf16-rounded features) / C4 / C5 shapes: the oracle reproduces
+    the stored subsample and checksums bit for bit (the seeded inputs are identified by their sha256)."""
+    wl, inp = baseline_golden_inputs(name, seed, bf16)
+    assert np.array_equal(_sha(inp["ref_feat"].numpy(), inp["nghbr_feat"].numpy(), inp["ref_gmms"].numpy(),
+                               inp["nghbr_gmms"].numpy(), inp["nghbr_poses"].numpy()), golden_r2[f"G2_{name}_input_sha"])
+    out = oracle.cost_volume_cw(None, inp["ref_gmms"], oracle.depth_sampling(3, wl.D), inp["ref_feat"], inp["nghbr_feat"],
+                                inp["nghbr_gmms"], inp["nghbr_poses"], inp["is_valid"], inp["cam_intrins"]["intM"],
+                                inp["cam_intrins"]["unit_ray_array_2D"], 5.0)
+    assert np.array_equal(out[:, ::3, ::5, ::7], golden_r2[f"G2_{name}_cost_sub"])
+    s = golden_r2[f"G2_{name}_cost_sum"]
+    assert out.astype(np.float64).sum() == s[0] and np.abs(out).astype(np.float64).sum() == s[1]
