@@ -74,7 +74,7 @@ typedef struct MagnetCostVolumeArgs {
     const float   *poses;                  /* (B,V,4,4) relative poses ref->source (utils.data_preprocess) */
     const int32_t *is_valid;               /* (B,V) */
     const float   *intM;                   /* (B,3,3) intrinsics at grid resolution */
-    const float   *rays;                   /* (B,3,h*w) unit_ray_array_2D */
+    const float   *rays;                   /* (B,3,h*w) unit_ray_array_2D; may be NULL when ray_params is given (path 0/1/2/4) */
     float         *cost;                   /* OUT (B,D,h,w) fp32; frame b starts at cost + b*cost_batch_stride */
     int32_t        path;                   /* kernel selection, low 8 bits:
                                               0 = auto: the PRODUCTION matcher (tolerance parity: gate-flip fraction <= 1e-5,
@@ -108,6 +108,12 @@ typedef struct MagnetCostVolumeArgs {
                                               (view, candidate, pixel) sample, homography.py:157-158 (1 = open).  Written by the
                                               production matcher (path 0/4) and by the exact candidate-lane kernel (path 2);
                                               entries of invalid views are not written (zero the buffer first).  NULL = off. */
+    const double  *ray_params;             /* optional DEVICE (B,8) float64 {fx, fy, cx, cy, sx, sy, left, top} of the RAW image
+                                              (sx = raw_w / w, sy = raw_h / h; left/top = crop margins, KITTI): with rays == NULL the
+                                              production and candidate-lane / generic kernels evaluate the loaders' expression
+                                              ((x+0.5)*sx - cx + left)/fx in float64 per reference pixel instead of reading the
+                                              12*h*w-byte table (dataloader_scannet.py:139-147, dataloader_kitti.py:113-118) —
+                                              bit-identical to it.  The worklist kernel and the backward need the table. */
 } MagnetCostVolumeArgs;
 
 MAGNET_API int magnet_version(void);
@@ -137,6 +143,16 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs *args, void *str
  * Depth bins, poses and intrinsics receive no gradient (they are data in the reference's training loop). */
 MAGNET_API int magnet_cost_volume_f_backward(const MagnetCostVolumeArgs *args, const float *grad_cost, float *grad_ref_cl,
                                   float *grad_src_pad, void *stream);
+
+/* ---- camera intrinsics and relative poses on the device (the loaders' / utils.data_preprocess' host work; row N4) ----
+ * magnet_make_rays: unit_ray_array_2D (B,3,h*w) fp32 from DEVICE ray_params (B,8) float64 {fx, fy, cx, cy, sx, sy, left, top}
+ *   (see MagnetCostVolumeArgs.ray_params; data/dataloader_scannet.py:113-153, dataloader_kitti.py:83-127, dataloader_7scenes.py:72-116).
+ * magnet_relative_poses: utils.data_preprocess (utils/utils.py:72-98): DEVICE float64 extrinsics ext_ref (B,4,4), ext_nghbr
+ *   (B,V,4,4) -> poses_out (B,V,4,4) fp32 = ext_nghbr @ inv(ext_ref) and is_valid_out (B,V) int32 (0 and a zero pose when either
+ *   matrix holds a NaN or the reference is singular).  Both outputs are what magnet_cost_volume_cw consumes. */
+MAGNET_API int magnet_make_rays(const double *ray_params, float *rays_out, int32_t B, int32_t h, int32_t w, void *stream);
+MAGNET_API int magnet_relative_poses(const double *ext_ref, const double *ext_nghbr, float *poses_out, int32_t *is_valid_out,
+                                     int32_t B, int32_t V, void *stream);
 
 /* gmm_out[:,0] = mu + o0*sigma ; gmm_out[:,1] = (elu(o1) + 1 + 1e-10)*sigma.   All (B,2,h*w) fp32.
  * gmm_out may alias gmm_in. */

@@ -20,6 +20,8 @@ hipError_t launch_space_to_depth(const uint16_t*, const uint16_t*, uint16_t*, ui
 hipError_t launch_avgpool_cl(const uint16_t*, const uint16_t*, int, int, int, int, int, int, int, uint16_t*, uint16_t*, hipStream_t);
 hipError_t launch_upsample_bilinear_cl(const float*, int, int, int, int, uint16_t*, uint16_t*, int, int, int, int, int, hipStream_t);
 hipError_t launch_depth_metrics(const float*, const float*, double*, int, int, float, float, hipStream_t);
+hipError_t launch_make_rays(const double*, float*, int, int, int, hipStream_t);
+hipError_t launch_relative_poses(const double*, const double*, float*, int32_t*, int, int, hipStream_t);
 }
 
 static thread_local char g_err[512] = "";
@@ -79,8 +81,11 @@ MAGNET_API int magnet_pack_gmm(const float* gmm_nchw, float* out_pad, int32_t N,
 static int cv_prepare(const MagnetCostVolumeArgs* a, magnet::CvParams& p, bool backward) {
     if (!a) return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: args is NULL");
     if (!a->ref_feat_cl || !a->src_feat_pad || (!a->src_gmm_pad && a->mode != 1) || !a->poses || !a->is_valid || !a->intM ||
-        !a->rays || (!backward && !a->cost && !a->cost_hi))
+        (!a->rays && !a->ray_params) || (!backward && !a->cost && !a->cost_hi))
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: a required pointer is NULL");
+    if (!a->rays && (backward || (a->path & 0xff) == 3))
+        return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: this kernel reads the ray table (ray_params alone serves path 0/1/2/4 forward): "
+                                   "build it with magnet_make_rays");
     if (a->mode != 0 && a->mode != 1) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: unknown mode %d", a->mode);
     if (a->mode == 1 && (!a->k_list || a->d_volume))
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: mode 1 takes its depth bins from k_list (d_volume must be NULL)");
@@ -116,6 +121,7 @@ static int cv_prepare(const MagnetCostVolumeArgs* a, magnet::CvParams& p, bool b
     p.intM = a->intM; p.rays = a->rays; p.cost = a->cost; p.stats = a->stats;
     p.cost_hi = (uint16_t*)a->cost_hi; p.cost_lo = (uint16_t*)a->cost_lo; p.cost_ld = a->cost_ld;
     p.gate_bits = a->gate_bits;
+    p.ray_params = a->rays ? nullptr : a->ray_params;           // the table wins when both are given
     if (a->cost_hi && (!a->cost_lo || a->cost_ld < a->D))
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: cost_hi needs cost_lo and cost_ld >= D");
     if (a->cost_hi && (a->path & 0xff) != 0 && (a->path & 0xff) != 2 && (a->path & 0xff) != 4)
@@ -179,6 +185,21 @@ MAGNET_API int magnet_cost_volume_f_backward(const MagnetCostVolumeArgs* a, cons
     if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_f_backward launch");
     if (!handled) return fail(MAGNET_E_DIM, "magnet_cost_volume_f_backward: shape not supported (F > 128, V > 31 or image too large)");
     return 0;
+}
+
+MAGNET_API int magnet_make_rays(const double* ray_params, float* rays_out, int32_t B, int32_t h, int32_t w, void* stream) {
+    if (!ray_params || !rays_out) return fail(MAGNET_E_NULL, "magnet_make_rays: NULL pointer");
+    if (B <= 0 || h <= 0 || w <= 0) return fail(MAGNET_E_DIM, "magnet_make_rays: bad dims B=%d h=%d w=%d", B, h, w);
+    hipError_t e = magnet::launch_make_rays(ray_params, rays_out, B, h, w, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_make_rays launch");
+}
+
+MAGNET_API int magnet_relative_poses(const double* ext_ref, const double* ext_nghbr, float* poses_out, int32_t* is_valid_out,
+                                     int32_t B, int32_t V, void* stream) {
+    if (!ext_ref || !ext_nghbr || !poses_out || !is_valid_out) return fail(MAGNET_E_NULL, "magnet_relative_poses: NULL pointer");
+    if (B <= 0 || V <= 0) return fail(MAGNET_E_DIM, "magnet_relative_poses: bad dims B=%d V=%d", B, V);
+    hipError_t e = magnet::launch_relative_poses(ext_ref, ext_nghbr, poses_out, is_valid_out, B, V, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_relative_poses launch");
 }
 
 MAGNET_API int magnet_gaussian_update(const float* gnet_out, const float* gmm_in, float* gmm_out, int32_t B, int32_t hw,

@@ -59,9 +59,9 @@ __global__ __launch_bounds__(256) void cv_generic_kernel(const CvParams p) {
     const size_t hw = (size_t)p.h * p.w;
     const size_t pix = (size_t)yc * p.w + xc;
 
-    const float r0 = p.rays[((size_t)b * 3 + 0) * hw + pix];
-    const float r1 = p.rays[((size_t)b * 3 + 1) * hw + pix];
-    const float r2 = p.rays[((size_t)b * 3 + 2) * hw + pix];
+    float r0, r1, r2;
+
+    load_ray(p, b, hw, xc, yc, r0, r1, r2);
     float mu = 0.f, sg = 0.f;
     if (!p.d_volume && !p.mode_f) {
         mu = p.ref_gmm[((size_t)b * 2 + 0) * hw + pix];

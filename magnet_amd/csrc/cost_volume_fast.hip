@@ -78,9 +78,8 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
         const int q = e & 15, v = e >> 4;
         const int xc = min(x_base + q, p.w - 1);
         const size_t pix = (size_t)yc * p.w + xc;
-        const float r0 = p.rays[((size_t)b * 3 + 0) * hw + pix];
-        const float r1 = p.rays[((size_t)b * 3 + 1) * hw + pix];
-        const float r2 = p.rays[((size_t)b * 3 + 2) * hw + pix];
+        float r0, r1, r2;
+        load_ray(p, b, hw, xc, yc, r0, r1, r2);
         const PixelView pv = make_pixel_view(p.intM + (size_t)b * 9, p.poses + ((size_t)b * p.V + v) * 16, r0, r1, r2);
         pvtab[e * 2 + 0] = make_float4(pv.rpx, pv.rpy, pv.rpz, pv.rcz);
         pvtab[e * 2 + 1] = make_float4(pv.kt0, pv.kt1, pv.kt2, pv.tz);

@@ -35,6 +35,7 @@ struct CvParams {
     long long      cost_ld;
     uint8_t*       gate_bits;         // optional debug output (B,V,D,h,w)
     int            npx;               // cost_volume_fast64.hip: pixels per wave (set by its launcher)
+    const double*  ray_params;        // optional (B,8) fx, fy, cx, cy, sx, sy, left, top: rays generated in the kernel
     float k[MAGNET_MAX_CANDIDATES];   // (float)k_j, read with wave-uniform indices (scalar loads)
 };
 
@@ -47,6 +48,24 @@ __device__ __forceinline__ GridConst grid_const(const CvParams& p) {
     gc.sw = (float)p.w / 2.0f;
     gc.sh = (float)p.h / 2.0f;
     return gc;
+}
+
+// unit ray of grid pixel (x, y) of frame b: the loader's table entry (dataloader_scannet.py:139-147, dataloader_kitti.py:113-118),
+// or — when the caller passed the 8 scalars instead of the 12*h*w-byte table — the same float64 expression evaluated here:
+// ((x + 0.5) * sx - cx + left) / fx, cast to fp32 once.  IEEE double mul / add / div (no contraction: -ffp-contract=off), so
+// the result equals the table bit for bit (tests/test_gpu_rays_poses.py).
+__device__ __forceinline__ void load_ray(const CvParams& p, int b, size_t hw, int x, int y, float& r0, float& r1, float& r2) {
+    if (p.ray_params) {
+        const double* q = p.ray_params + (size_t)b * 8;
+        r0 = (float)(((((double)x + 0.5) * q[4]) - q[2] + q[6]) / q[0]);
+        r1 = (float)(((((double)y + 0.5) * q[5]) - q[3] + q[7]) / q[1]);
+        r2 = 1.0f;
+    } else {
+        const size_t pix = (size_t)y * p.w + x;
+        r0 = p.rays[((size_t)b * 3 + 0) * hw + pix];
+        r1 = p.rays[((size_t)b * 3 + 1) * hw + pix];
+        r2 = p.rays[((size_t)b * 3 + 2) * hw + pix];
+    }
 }
 
 // XCD-aware block -> (tile, frame) map.  Hardware round-robins consecutive block ids over the 8

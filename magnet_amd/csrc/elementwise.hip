@@ -326,4 +326,78 @@ hipError_t launch_upsample(const float* d, const float* m, float* o, int B, int 
     }
 }
 
+// ---- camera intrinsics / relative poses on the device (row N4 of SURVEY.md §8f) ----------------------------------------------
+// unit_ray_array_2D (B,3,h*w) from (fx, fy, cx, cy, sx, sy, left, top) per frame: the loaders' float64 expression
+// ((x + 0.5) * sx - cx + left) / fx cast to fp32 once (dataloader_scannet.py:139-147, dataloader_kitti.py:113-118,
+// dataloader_7scenes.py:100-108): bit-identical to the host table.
+__global__ __launch_bounds__(256) void make_rays_kernel(const double* __restrict__ prm, float* __restrict__ rays, int B, int h, int w) {
+    const size_t hw = (size_t)h * w;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= hw * (size_t)B) return;
+    const int b = (int)(i / hw);
+    const size_t pix = i % hw;
+    const int y = (int)(pix / w), x = (int)(pix % w);
+    const double* q = prm + (size_t)b * 8;
+    rays[((size_t)b * 3 + 0) * hw + pix] = (float)(((((double)x + 0.5) * q[4]) - q[2] + q[6]) / q[0]);
+    rays[((size_t)b * 3 + 1) * hw + pix] = (float)(((((double)y + 0.5) * q[5]) - q[3] + q[7]) / q[1]);
+    rays[((size_t)b * 3 + 2) * hw + pix] = 1.0f;
+}
+
+hipError_t launch_make_rays(const double* prm, float* rays, int B, int h, int w, hipStream_t s) {
+    const size_t n = (size_t)B * h * w;
+    hipLaunchKernelGGL(make_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prm, rays, B, h, w);
+    return hipGetLastError();
+}
+
+// utils.data_preprocess (utils/utils.py:72-98): pose[b,v] = ext_nghbr[b,v] @ inv(ext_ref[b]) in float64, stored fp32; a NaN anywhere
+// in either matrix (ScanNet's lost poses) or a singular reference -> is_valid = 0 and a zero pose.  One thread per (b, v):
+// Gauss-Jordan with partial pivoting on the 4x4 reference (float64; agrees with LAPACK's inverse to a few ulp of float64,
+// i.e. identical after the cast to fp32 except for rare 1-ulp cases — test tolerance 1e-6).
+__global__ void relative_poses_kernel(const double* __restrict__ ext_ref, const double* __restrict__ ext_ngh,
+                                      float* __restrict__ poses, int32_t* __restrict__ valid, int B, int V) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * V) return;
+    const int b = i / V;
+    double a[4][8];
+    bool bad = false;
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            a[r][c] = ext_ref[(size_t)b * 16 + r * 4 + c];
+            a[r][4 + c] = (r == c) ? 1.0 : 0.0;
+            bad |= (a[r][c] != a[r][c]);
+        }
+    double n[16];
+    for (int e = 0; e < 16; ++e) { n[e] = ext_ngh[(size_t)i * 16 + e]; bad |= (n[e] != n[e]); }
+    if (!bad) {
+        for (int c = 0; c < 4 && !bad; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+            if (!(fabs(a[piv][c]) > 0.0)) { bad = true; break; }
+            if (piv != c) for (int k = 0; k < 8; ++k) { const double t = a[c][k]; a[c][k] = a[piv][k]; a[piv][k] = t; }
+            const double inv = 1.0 / a[c][c];
+            for (int k = 0; k < 8; ++k) a[c][k] *= inv;
+            for (int r = 0; r < 4; ++r) {
+                if (r == c) continue;
+                const double f = a[r][c];
+                for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
+            }
+        }
+    }
+    float out[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc += n[r * 4 + k] * a[k][4 + c];
+            bad |= (acc != acc);
+            out[r * 4 + c] = (float)acc;
+        }
+    for (int e = 0; e < 16; ++e) poses[(size_t)i * 16 + e] = bad ? 0.0f : out[e];
+    valid[i] = bad ? 0 : 1;
+}
+
+hipError_t launch_relative_poses(const double* ext_ref, const double* ext_ngh, float* poses, int32_t* valid, int B, int V, hipStream_t s) {
+    hipLaunchKernelGGL(relative_poses_kernel, dim3((unsigned)((B * V + 63) / 64)), dim3(64), 0, s, ext_ref, ext_ngh, poses, valid, B, V);
+    return hipGetLastError();
+}
+
 }  // namespace magnet

@@ -39,23 +39,48 @@ def read_pose_txt(path: str) -> np.ndarray:
             return np.full((4, 4), np.nan)
 
 
-def cam_intrinsics(K: np.ndarray, raw_w: int, raw_h: int, dpv_h: int, dpv_w: int) -> dict:
-    """K (>=3x3, pixels of the raw_w x raw_h image) -> {'intM' (3,3), 'unit_ray_array_2D' (3, dpv_h*dpv_w)} fp32:
-    intrinsics scaled to the matching grid and the ray ((x+0.5)*sx - cx)/fx, ((y+0.5)*sy - cy)/fy, 1 of every grid pixel,
-    row-major (dataloader_scannet.py:113-153; float64 math, one cast)."""
+def cam_intrinsics(K: np.ndarray, raw_w: int, raw_h: int, dpv_h: int, dpv_w: int, crop=(0, 0), with_table: bool = True) -> dict:
+    """K (>=3x3, pixels of the image the network sees BEFORE any crop) -> {'intM' (3,3), 'unit_ray_array_2D' (3, dpv_h*dpv_w),
+    'ray_params' (8,) float64}: intrinsics scaled to the matching grid and the ray ((x+0.5)*sx - cx + left)/fx,
+    ((y+0.5)*sy - cy + top)/fy, 1 of every grid pixel, row-major (float64 math, one cast).
+      ScanNet / 7-Scenes (dataloader_scannet.py:113-153, dataloader_7scenes.py:72-116): raw_w x raw_h = the raw image, no crop.
+      KITTI (dataloader_kitti.py:83-127): raw_w x raw_h = the CROPPED network input (1216 x 352), crop = (left, top) margins of the
+      KB crop inside the raw frame — see cam_intrinsics_kitti.
+    'ray_params' = (fx, fy, cx, cy, sx, sy, left, top): what the kernel needs to generate the rays itself (the 12*h*w-byte
+    table then never exists: pass with_table=False)."""
     K = np.asarray(K, dtype=np.float64)
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    left, top = float(crop[0]), float(crop[1])
     intM = np.zeros((3, 3))
     intM[2, 2] = 1.0
     intM[0, 0], intM[1, 1] = fx * (dpv_w / raw_w), fy * (dpv_h / raw_h)
-    intM[0, 2], intM[1, 2] = cx * (dpv_w / raw_w), cy * (dpv_h / raw_h)
-    xs = np.arange(dpv_w, dtype=np.float64)[None, :] + 0.5
-    ys = np.arange(dpv_h, dtype=np.float64)[:, None] + 0.5
-    rays = np.ones((3, dpv_h, dpv_w))
-    rays[0] = (xs * (raw_w / dpv_w) - cx) / fx
-    rays[1] = (ys * (raw_h / dpv_h) - cy) / fy
-    return {"intM": torch.from_numpy(intM.astype(np.float32)),
-            "unit_ray_array_2D": torch.from_numpy(rays.reshape(3, -1).astype(np.float32))}
+    intM[0, 2], intM[1, 2] = (cx - left) * (dpv_w / raw_w), (cy - top) * (dpv_h / raw_h)
+    sx, sy = raw_w / dpv_w, raw_h / dpv_h
+    out = {"intM": torch.from_numpy(intM.astype(np.float32)),
+           "ray_params": torch.tensor([fx, fy, cx, cy, sx, sy, left, top], dtype=torch.float64)}
+    if with_table:
+        xs = np.arange(dpv_w, dtype=np.float64)[None, :] + 0.5
+        ys = np.arange(dpv_h, dtype=np.float64)[:, None] + 0.5
+        rays = np.ones((3, dpv_h, dpv_w))
+        rays[0] = (xs * sx - cx + left) / fx
+        rays[1] = (ys * sy - cy + top) / fy
+        out["unit_ray_array_2D"] = torch.from_numpy(rays.reshape(3, -1).astype(np.float32))
+    return out
+
+
+def cam_intrinsics_kitti(K_cam2: np.ndarray, raw_w: int, raw_h: int, dpv_h: int, dpv_w: int, img_h: int = 352, img_w: int = 1216,
+                         with_table: bool = True) -> dict:
+    """KITTI (dataloader_kitti.py:94-127): the network input is the 1216 x 352 KB crop of the raw_w x raw_h frame
+    (top margin raw_h - 352, left margin (raw_w - 1216) / 2, both truncated to int); K_cam2 is the raw calibration."""
+    top = int(raw_h - img_h)
+    left = int((raw_w - img_w) / 2)
+    return cam_intrinsics(K_cam2, img_w, img_h, dpv_h, dpv_w, crop=(left, top), with_table=with_table)
+
+
+def cam_intrinsics_7scenes(dpv_h: int, dpv_w: int, img_h: int = 480, img_w: int = 640, with_table: bool = True) -> dict:
+    """7-Scenes (dataloader_7scenes.py:83-116): fixed fx = fy = 585, principal point (320, 240) of the 640 x 480 frames."""
+    K = np.array([[585.0, 0.0, 320.0], [0.0, 585.0, 240.0], [0.0, 0.0, 1.0]])
+    return cam_intrinsics(K, img_w, img_h, dpv_h, dpv_w, with_table=with_table)
 
 
 def window_indices(center: int, n_views: int, window_radius: int, exists) -> list:

@@ -29,7 +29,13 @@ _VALID_CACHE: dict = {}
 def _to_device_cached(t: torch.Tensor, device, dtype, cache: dict):
     if t.is_cuda:
         return t.to(device=device, dtype=dtype).contiguous()
-    key = (t.data_ptr(), t._version, tuple(t.shape), str(device), dtype)
+    # key on the CONTENT for small tensors (intM: 36 B per frame) and on a strided content sample for the ray table: a tensor
+    # from torch.from_numpy whose array is rewritten through numpy keeps data_ptr and _version
+    tc = t.contiguous()
+    flat = tc.view(-1)
+    sample = flat if flat.numel() <= 4096 else flat[:: max(1, flat.numel() // 1024)]
+    key = (t.data_ptr(), t._version, tuple(t.shape), str(device), dtype, bytes(sample.numpy().tobytes()),
+           float(flat[-1]) if flat.numel() else 0.0)
     hit = cache.get(key)
     if hit is not None and hit[0]() is t:
         return hit[1]
@@ -95,7 +101,15 @@ class CostVolumeCW:
         self.poses = nghbr_poses.detach().to(device=dev, dtype=torch.float32).contiguous()
         self.is_valid = _valid_to_device(is_valid, dev)
         self.intM = _to_device_cached(cam_intrins["intM"], dev, torch.float32, _INTRINS_CACHE)
-        self.rays = _to_device_cached(cam_intrins["unit_ray_array_2D"], dev, torch.float32, _INTRINS_CACHE)
+        # rays: the loader's (B,3,h*w) table, or — when the dict only carries 'ray_params' (B,8) float64 (magnet_amd.data
+        # with_table=False) — generated inside the kernel from those 8 scalars (worklist kernel: table built on the device)
+        self.rays, self.ray_params = None, None
+        if "unit_ray_array_2D" in cam_intrins:
+            self.rays = _to_device_cached(cam_intrins["unit_ray_array_2D"], dev, torch.float32, _INTRINS_CACHE)
+        else:
+            self.ray_params = _to_device_cached(cam_intrins["ray_params"], dev, torch.float64, _INTRINS_CACHE)
+            if (path & 0xff) == 3:
+                self.rays = lib.make_rays(self.ray_params, self.h, self.w)
         self.kappa = float(thres)
         self.path = path
 
@@ -111,7 +125,7 @@ class CostVolumeCW:
         res = lib.cost_volume_cw(self.ref_cl, self.src_pad, self.src_gmm_pad, self.poses, self.is_valid,
                                  self.intM, self.rays, self.kappa, ref_gmm=ref_gmm, k_list=k_list,
                                  d_volume=d_volume, out=out, path=self.path, stats=stats, out_split=out_split,
-                                 gate_bits=gate_bits)
+                                 gate_bits=gate_bits, ray_params=self.ray_params)
         if sink is not None:
             e1.record()
             sink.append((e0, e1))

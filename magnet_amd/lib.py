@@ -45,6 +45,7 @@ class MagnetCostVolumeArgs(ctypes.Structure):
         ("cost_hi", ctypes.c_void_p), ("cost_lo", ctypes.c_void_p), ("cost_ld", ctypes.c_int64),
         ("mode", ctypes.c_int32),
         ("gate_bits", ctypes.c_void_p),
+        ("ray_params", ctypes.c_void_p),
     ]
 
 
@@ -149,7 +150,7 @@ def pack_gmm(gmm_nchw: torch.Tensor, out: torch.Tensor | None = None):
 
 def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM, rays, kappa,
                    ref_gmm=None, k_list=None, d_volume=None, out=None, path: int = 0, stats=None, out_split=None,
-                   mode: int = 0, gate_bits=None):
+                   mode: int = 0, gate_bits=None, ray_params=None):
     """Launch the fused matching kernel.  All tensors on one GPU; see MagnetCostVolumeArgs.
 
     ref_feat_cl (B,h,w,F) from pack_features(pad=0); src_feat_pad (V*B,h+2,w+2,F) from
@@ -198,12 +199,23 @@ def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM
             a.ref_gmm = rg.data_ptr(); keep.append(rg)
     a.D = D
     po = _dev(poses, "poses", torch.float32); iv = _dev(is_valid, "is_valid", torch.int32)
-    K = _dev(intM, "intM", torch.float32); ry = _dev(rays, "rays", torch.float32)
-    if tuple(po.shape) != (B, V, 4, 4) or tuple(iv.shape) != (B, V) or tuple(K.shape) != (B, 3, 3) \
-            or tuple(ry.shape) != (B, 3, h * w):
-        raise MagnetError("poses/is_valid/intM/rays shape mismatch: "
-                          f"{tuple(po.shape)} {tuple(iv.shape)} {tuple(K.shape)} {tuple(ry.shape)}")
-    a.poses, a.is_valid, a.intM, a.rays = po.data_ptr(), iv.data_ptr(), K.data_ptr(), ry.data_ptr()
+    K = _dev(intM, "intM", torch.float32)
+    if rays is None and ray_params is None:
+        raise MagnetError("need rays (B,3,h*w) or ray_params (B,8) float64")
+    if rays is not None:
+        ry = _dev(rays, "rays", torch.float32)
+        if tuple(ry.shape) != (B, 3, h * w):
+            raise MagnetError(f"rays shape {tuple(ry.shape)}, expected {(B, 3, h * w)}")
+        a.rays = ry.data_ptr()
+    else:
+        ry = _dev(ray_params, "ray_params", torch.float64)                 # the kernel generates the rays (N4)
+        if tuple(ry.shape) != (B, 8):
+            raise MagnetError(f"ray_params shape {tuple(ry.shape)}, expected {(B, 8)}")
+        a.ray_params = ry.data_ptr()
+    if tuple(po.shape) != (B, V, 4, 4) or tuple(iv.shape) != (B, V) or tuple(K.shape) != (B, 3, 3):
+        raise MagnetError("poses/is_valid/intM shape mismatch: "
+                          f"{tuple(po.shape)} {tuple(iv.shape)} {tuple(K.shape)}")
+    a.poses, a.is_valid, a.intM = po.data_ptr(), iv.data_ptr(), K.data_ptr()
     if out_split is not None:
         # (hi, lo, ld): split-bf16 planes of the conv kernel's zero-bordered channel-last buffer, written in place
         oh, ol, ld = out_split
@@ -453,7 +465,41 @@ def conv1x1_chain(in_hi, in_lo, w_hi, w_lo, bias, out, rows, cout_pad):
                                         _stream(in_hi)), "magnet_conv1x1_chain")
 
 
-API_SYMBOLS = API_SYMBOLS + ("magnet_depth_metrics",)
+API_SYMBOLS = API_SYMBOLS + ("magnet_depth_metrics", "magnet_make_rays", "magnet_relative_poses")
+
+
+def make_rays(ray_params, h: int, w: int):
+    """(B,8) float64 GPU {fx, fy, cx, cy, sx, sy, left, top} -> unit_ray_array_2D (B,3,h*w) fp32 on the device, bit-identical to
+    the loaders' host table (dataloader_scannet.py:139-147, dataloader_kitti.py:113-118)."""
+    lib = load()
+    prm = _dev(ray_params, "ray_params", torch.float64)
+    if prm.dim() != 2 or prm.shape[1] != 8:
+        raise MagnetError(f"ray_params shape {tuple(prm.shape)}, expected (B, 8)")
+    B = prm.shape[0]
+    out = torch.empty((B, 3, h * w), dtype=torch.float32, device=prm.device)
+    lib.magnet_make_rays.restype = ctypes.c_int
+    lib.magnet_make_rays.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    with torch.cuda.device(prm.device):
+        _check(lib.magnet_make_rays(prm.data_ptr(), out.data_ptr(), B, int(h), int(w), _stream(prm)), "magnet_make_rays")
+    return out
+
+
+def relative_poses(ext_ref, ext_nghbr):
+    """utils.data_preprocess on the device (utils/utils.py:72-98): float64 GPU extrinsics ext_ref (B,4,4), ext_nghbr (B,V,4,4) ->
+    (poses (B,V,4,4) fp32, is_valid (B,V) int32), both on the device, ready for the matcher."""
+    lib = load()
+    er = _dev(ext_ref, "ext_ref", torch.float64); en = _dev(ext_nghbr, "ext_nghbr", torch.float64)
+    if er.dim() != 3 or tuple(er.shape[1:]) != (4, 4) or en.dim() != 4 or en.shape[0] != er.shape[0] or tuple(en.shape[2:]) != (4, 4):
+        raise MagnetError(f"relative_poses: shapes {tuple(er.shape)} {tuple(en.shape)}, expected (B,4,4) and (B,V,4,4)")
+    B, V = en.shape[:2]
+    poses = torch.empty((B, V, 4, 4), dtype=torch.float32, device=er.device)
+    valid = torch.empty((B, V), dtype=torch.int32, device=er.device)
+    lib.magnet_relative_poses.restype = ctypes.c_int
+    lib.magnet_relative_poses.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    with torch.cuda.device(er.device):
+        _check(lib.magnet_relative_poses(er.data_ptr(), en.data_ptr(), poses.data_ptr(), valid.data_ptr(), B, V, _stream(er)),
+               "magnet_relative_poses")
+    return poses, valid
 
 
 # ---- F-Net non-GEMM layers (row N3) -------------------------------------------------------------------------------

@@ -12,6 +12,19 @@ def split_data_array(data_array):
     return data_array[ref_idx], [data_array[idx] for idx in range(n_frames) if idx != ref_idx]
 
 
+def data_preprocess_device(data_array, cur_batch_size, device):
+    """data_preprocess with the float64 inverse / product / NaN test on the GPU (lib.relative_poses): the extrinsics go up as
+    (V+1) x B x 128 bytes, poses and is_valid never come back to the host — they are what the matcher reads.
+    Returns (ref_dat, nghbr_dats, nghbr_poses (B,V,4,4) fp32 cuda, is_valid (B,V) int32 cuda)."""
+    from . import lib
+    ref_dat, nghbr_dats = split_data_array(data_array)
+    B = cur_batch_size
+    ref = torch.as_tensor(ref_dat["extM"]).double()[:B].to(device)
+    ngh = torch.stack([torch.as_tensor(d["extM"]).double()[:B] for d in nghbr_dats], 1).to(device)
+    poses, valid = lib.relative_poses(ref.contiguous(), ngh.contiguous())
+    return ref_dat, nghbr_dats, poses, valid
+
+
 def data_preprocess(data_array, cur_batch_size):
     ref_dat, nghbr_dats = split_data_array(data_array)
     num_views = len(nghbr_dats)

@@ -96,3 +96,19 @@ def test_seven_scenes_layout(tmp_path):
     data_array, cam = next(data.batches(ds, 1))
     _, _, poses, valid = data_preprocess(data_array, 1)
     assert valid.tolist() == [[1, 1]] and poses.shape == (1, 2, 4, 4)
+
+
+def test_cam_intrinsics_match_reference_loaders(golden_r2):
+    """G12: intM and the unit-ray table of the ScanNet / 7-Scenes / KITTI loaders (computed by the reference's own methods,
+    tests/golden/make_golden_r2.py) — reproduced bit for bit, including KITTI's KB-crop margins."""
+    import numpy as np
+    from magnet_amd import data
+    g = golden_r2
+    ci = data.cam_intrinsics(g["G12_scannet_K"], 1296, 968, 120, 160)
+    assert np.array_equal(ci["intM"].numpy(), g["G12_scannet_intM"]) and np.array_equal(ci["unit_ray_array_2D"].numpy(), g["G12_scannet_rays"])
+    ci = data.cam_intrinsics_7scenes(120, 160)
+    assert np.array_equal(ci["intM"].numpy(), g["G12_7scenes_intM"]) and np.array_equal(ci["unit_ray_array_2D"].numpy(), g["G12_7scenes_rays"])
+    ci = data.cam_intrinsics_kitti(g["G12_kitti_K"], 1242, 375, 88, 304)
+    assert np.array_equal(ci["intM"].numpy(), g["G12_kitti_intM"]) and np.array_equal(ci["unit_ray_array_2D"].numpy(), g["G12_kitti_rays"])
+    assert ci["ray_params"].dtype.is_floating_point and tuple(ci["ray_params"].shape) == (8,) and float(ci["ray_params"][6]) == 13.0 and float(ci["ray_params"][7]) == 23.0
+    assert "unit_ray_array_2D" not in data.cam_intrinsics_7scenes(120, 160, with_table=False)
