@@ -172,6 +172,9 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="run the mask head on a side stream (measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-only", action="store_true", help="step = the fused cost-volume kernel alone")
+    ap.add_argument("--packed-inputs", action="store_true", help="backbone outputs arrive in the kernels' layouts (features "
+                    "channel-last as the matrix-core F-Net writes them, x_d3 in the G-Net input buffer): no pack pass in the step")
+    ap.add_argument("--overlap-pack", action="store_true", help="x_d3 repack on a side stream beside the matcher (measured: no gain)")
     ap.add_argument("--sustain-s", type=float, default=2.0, help="extra untimed-by-contract run of this many seconds after the K "
                     "steps, reported as sustained_frames_per_s (0 = skip)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / distributed self-test without a GPU: gloo backend, "
@@ -215,6 +218,7 @@ def main():
         model_cpu = copy.deepcopy(model).eval()
     model = model.to(device).eval()
     model.overlap_mask_head = a.overlap
+    model.overlap_pack = a.overlap_pack
     model.fuse_conv_tail = not a.no_fuse_tail
     bcast_bytes = mdist.broadcast_module_(model, src=0)   # the one RCCL collective (weights), xGMI
 
@@ -240,6 +244,19 @@ def main():
 
         def step(timed):
             graphed(*graphed.static)                        # inputs already in place: replay only
+    elif a.packed_inputs:
+        # what a backbone on the matrix-core path hands over: features in the matcher's layouts (magnet_amd/fnet.py writes
+        # exactly these), x_d3 already in the G-Net input buffer.  Packed ONCE, outside the timed region.
+        packed = (lib.pack_features(inp["ref_feat"], lib.feat_enum(fdt), pad=0), lib.pack_features(inp["nghbr_feat"], lib.feat_enum(fdt), pad=1))
+        gh, gl, ctot, coff = model.gnet_input_buffer(B, wl.h, wl.w, device)
+        lib.pack_split(inp["x_d3"], gh, gl, ctot, coff)
+
+        def step(timed):
+            CostVolumeCW.event_sink = ev_pairs if timed else None
+            ConvStackMFMA.event_sink = conv_events if timed else None
+            with torch.no_grad():
+                model.match_and_refine(inp["ref_gmms"], None, None, None, inp["nghbr_gmms"], inp["nghbr_poses"], inp["is_valid"],
+                                       inp["cam_intrins"], mode="test", packed_feats=packed, x_d3_in_place=True)
     else:
         def step(timed):
             CostVolumeCW.event_sink = ev_pairs if timed else None
@@ -310,6 +327,8 @@ def main():
             "config": {"workload": workload_desc,
                        "feature_storage": fdt, "arithmetic": "fp32 (matcher: fp32 view accumulation, tolerance-parity geometry; convolutions "
                                                              "bf16x3-split on the matrix cores with fp32 accumulation)",
+                       "inputs": ("backbone outputs in the kernels' layouts (no pack pass)" if a.packed_inputs else
+                                  "backbone outputs as the reference's NCHW fp32 tensors (pack passes inside the step)"),
                        "frames_per_gpu_per_step": B, "step": "kernel-only" if a.kernel_only else
                        ("pack + I x (fused cost volume + G-Net + Gaussian update) + mask head + convex upsample; convs on "
                         + ("the bf16x3 MFMA kernel" if a.conv_backend == "mfma" else "MIOpen fp32")),

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "cv_common.hpp"
 #include "conv_common.hpp"
 
@@ -283,6 +284,7 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     p.repad = a->repad;
     p.tail_w_hi = (const uint16_t*)a->tail_w_hi; p.tail_w_lo = (const uint16_t*)a->tail_w_lo; p.tail_bias = a->tail_bias;
     p.tail_cout = a->tail_cout_pad;
+    { static const int dev_variant = getenv("MAGNET_CONV_VARIANT") ? atoi(getenv("MAGNET_CONV_VARIANT")) : 0; p.variant = dev_variant; }   // dev A/B switch
     hipError_t e = magnet::launch_conv_mfma(p, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_conv_mfma launch");
 }

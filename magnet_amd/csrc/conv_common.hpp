@@ -30,6 +30,7 @@ struct ConvParams {
     // workgroup's tile before it leaves the CU; weights [128][128],[128][128],[tail_cout][128] concatenated, bias likewise
     const uint16_t* tail_w_hi; const uint16_t* tail_w_lo; const float* tail_bias;
     int tail_cout;                                    // 16, 128 or 144; result fp32 (rows, tail_cout) at out_f32
+    int variant;                                      // dev: bit 1 = 8-wave ping-pong K loop (conv_mfma.hip, PP) instead of the default
 };
 
 struct ChainParams {

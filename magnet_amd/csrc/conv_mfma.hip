@@ -119,12 +119,18 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
 }
 
 // TAIL = 0: plain layer.  TAIL = 16-column fragments of the fused tail's last layer (1, 8 or 9): see ConvParams::tail_*.
-template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+// PP = "ping-pong" K loop: NT = 512 threads = 8 waves = two wave groups (waves 0-3 / 4-7: one wave of each group per SIMD) that
+// run the same program half a K step apart — while one group issues its fragment reads and the LDS-DMA of the stage two steps
+// ahead, the other owns the matrix pipe — over a 3-slot LDS ring with counted vmcnt waits and raw s_barriers (no DMA drain at a
+// barrier).  The 4-wave / 2-slot loop (PP = false) drains the DMA queue (vmcnt(0)) at every step's __syncthreads and relies on a
+// second workgroup per CU to fill the gap: 41 % of the matrix pipe; see DESIGN.md §4.3.
+template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false>
+__global__ __launch_bounds__(NT) void conv_mfma_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins do not exist in the host pass (which only needs the stub)
     constexpr int BN = NF * 16;
-    constexpr int A_PT = CV_BM / 64;                           // 16-byte vectors per thread per A plane (2 or 4)
-    constexpr int WM = 4 / WN;                        // waves along M
+    constexpr int RP = NT / 4;                        // tile rows filled by one DMA instruction per wave set (4 lanes per 64-byte row)
+    constexpr int A_PT = CV_BM / RP;                           // 16-byte vectors per thread per A plane (2 or 4)
+    constexpr int WM = (NT / 64) / WN;                // waves along M
     constexpr int MF = CV_BM / (WM * 16);             // M fragments per wave (2 or 4)
     constexpr int NFW = NF / WN;                      // N fragments per wave
     static_assert(NF % WN == 0, "N fragments must split evenly over the waves");
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     // 64-byte K-slice of one row = 4 x 16 B; thread -> (row = tid>>2 (+64, +128 ...), physical slot = tid&3).  The DMA
     // writes lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the SOURCE: the lane
     // that fills physical slot ps of row r fetches logical K slot ps ^ ((r>>1)&3)  (cdna_hip_programming.md rule 21).
-    constexpr int B_PT = (BN * 4 + 255) / 256;                 // 16-byte vectors per thread per B plane
+    constexpr int B_PT = (BN + RP - 1) / RP;                   // 16-byte vectors per thread per B plane
     const int ksteps_per_tap = p.cin / CV_BK;
     const int nsteps = p.taps * ksteps_per_tap;
     const int st_r = tid >> 2, st_q = tid & 3;
@@ -178,9 +184,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const __amdgpu_buffer_rsrc_t rb_lo = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_lo, 0, w_bytes, flags);
     int a_v[A_PT], b_v[B_PT];                                  // per-lane byte offsets, constant over the K loop
 #pragma unroll
-    for (int i = 0; i < A_PT; ++i) a_v[i] = (((int)(row0 - base_row) + st_r + i * 64) * p.in_ld + st_k) * 2;
+    for (int i = 0; i < A_PT; ++i) a_v[i] = (((int)(row0 - base_row) + st_r + i * RP) * p.in_ld + st_k) * 2;
 #pragma unroll
-    for (int i = 0; i < B_PT; ++i) b_v[i] = ((n0 + st_r + i * 64) * p.cin + st_k) * 2;
+    for (int i = 0; i < B_PT; ++i) b_v[i] = ((n0 + st_r + i * RP) * p.cin + st_k) * 2;
     int pf_tap = 0, pf_ty = 0, pf_tx = 0, pf_k0 = 0;           // (tap = ty*n+tx, first channel) of the next stage to fetch
     typedef void __attribute__((address_space(3)))* lptr_t;
 #define CV_BLDS(rsrc, lp, voff) __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lptr_t)(lp), 16, (voff), 0, 0, 0)
@@ -193,13 +199,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         const int a_u = (((pf_ty + p.tap_o0) * p.tap_sy + (pf_tx + p.tap_o0) * p.tap_sx) * p.in_ld + pf_k0) * 2;    \
         const int b_u = (pf_tap * p.cout_pad * p.cin + pf_k0) * 2;                                     \
         _Pragma("unroll") for (int i = 0; i < A_PT; ++i) {                                             \
-            CV_BLDS(ra_hi, sa_hi + (wave_row + i * 64) * CV_ROW, a_v[i] + a_u);                        \
-            CV_BLDS(ra_lo, sa_lo + (wave_row + i * 64) * CV_ROW, a_v[i] + a_u);                        \
+            CV_BLDS(ra_hi, sa_hi + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);                        \
+            CV_BLDS(ra_lo, sa_lo + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);                        \
         }                                                                                              \
         _Pragma("unroll") for (int i = 0; i < B_PT; ++i) {                                             \
-            if (st_r + i * 64 < BN) {                                                                  \
-                CV_BLDS(rb_hi, sb_hi + (wave_row + i * 64) * CV_ROW, b_v[i] + b_u);                    \
-                CV_BLDS(rb_lo, sb_lo + (wave_row + i * 64) * CV_ROW, b_v[i] + b_u);                    \
+            if (st_r + i * RP < BN) {                                                                  \
+                CV_BLDS(rb_hi, sb_hi + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);                    \
+                CV_BLDS(rb_lo, sb_lo + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);                    \
             }                                                                                          \
         }                                                                                              \
         ++pf_tap;                                                                                      \
@@ -245,6 +251,70 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         }
     };
 
+    if constexpr (PP) {
+        static_assert(NT == 512 && BN % RP == 0 && CV_BM % RP == 0 && A_PT + B_PT <= NFW, "ping-pong loop: 8 waves, whole DMA passes, one DMA pass per N fragment");
+        constexpr int GL = 2 * A_PT + 2 * B_PT;               // LDS-DMA instructions per wave and stage
+        // fragments of one stage: read in the LOAD phase, consumed in the COMPUTE phase
+        bf16x8_t fah[MF], fal[MF], fbh[NFW], fbl[NFW];
+        auto load_frags = [&](int buf) {
+            const unsigned char* sa_hi = smem + buf * STAGE_BYTES;
+            const unsigned char* sa_lo = sa_hi + A_BYTES;
+            const unsigned char* sb_hi = sa_hi + 2 * A_BYTES;
+            const unsigned char* sb_lo = sb_hi + B_BYTES;
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                fah[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa_hi + a_off + m * 16 * CV_ROW));
+                fal[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa_lo + a_off + m * 16 * CV_ROW));
+            }
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+                fbh[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
+                fbl[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_lo + b_off + n * 16 * CV_ROW));
+            }
+        };
+        const int grp = __builtin_amdgcn_readfirstlane(wv >> 2);
+        if (0 < nsteps) CV_DMA(0, 0)
+        if (1 < nsteps) CV_DMA(1, 1)
+        if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");   // stage 0 landed (this wave's pieces)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // ... and every other wave's
+        if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier (= half a step) behind group 0
+        int slot = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            // ---- LOAD phase (the other group computes meanwhile) ----
+            asm volatile("" ::: "memory");
+            load_frags(slot);
+            // refill the slot last read one step ago: both groups' reads of it retired (lgkmcnt(0)) before barriers this wave
+            // has passed since.  (Issuing the DMA pieces between the MFMAs of the compute phase instead was measured slower:
+            // 6.15 vs 5.83 ms of convolutions per C2 step.)
+            const int nslot = slot == 0 ? 2 : slot - 1;       // (slot + 2) % 3
+            if (s + 2 < nsteps) {
+                CV_DMA(s + 2, nslot)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");             // stage s+1 landed; stage s+2 stays in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- COMPUTE phase ----
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[m], fbh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[m], fbl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[m], fbh[n], acc[m][n], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();           // balance group 1's extra barrier
+        __syncthreads();                                      // nothing in flight (last waits were vmcnt(0)): the ring is dead
+    } else {
 #pragma unroll
     for (int q = 0; q < SPB; ++q)
         if (q < nsteps) CV_DMA(q, q)
@@ -260,12 +330,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             if (s + q < nsteps) compute(half * SPB + q);
         __syncthreads();                                      // next half landed; everyone done with this half
     }
+    }
 
     if constexpr (TAIL > 0) {
         // ---- fused 1x1 tail: the 128 x 128 tile (bias, ReLU, re-split) becomes the LDS-resident input of three 1x1 layers ----
-        static_assert(NF == 8 && WN == 2 && CV_BM == 128, "the fused tail is written for the 128 x 128 tile");
-        unsigned char* act_hi = smem;                                   // [128 rows][256 B]; the K ring is dead (barrier above)
-        unsigned char* act_lo = smem + 128 * 256;
+        static_assert(NF == 8 && WN == 2 && (CV_BM == 128 || CV_BM == 256) && CV_BM == (NT / 64) * 32,
+                      "the fused tail is written for 128-channel tiles with 32 rows per wave");
+        unsigned char* act_hi = smem;                                   // [CV_BM rows][256 B]; the K ring is dead (barrier above)
+        unsigned char* act_lo = smem + CV_BM * 256;
 #pragma unroll
         for (int m = 0; m < MF; ++m)
 #pragma unroll
@@ -387,24 +459,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #endif
 }
 
-template <int NF, int WN, int BM, int SPB>
+template <int NF, int WN, int BM, int SPB, int NT = 256, bool PP = false>
 static size_t conv_lds_bytes() {
-    const size_t tiles = 2 * SPB * (2 * (size_t)BM * CV_ROW + 2 * (size_t)(NF * 16) * CV_ROW);
-    const size_t stage = (size_t)4 * 16 * ((NF / WN) * 16 + 4) * 4;
+    const size_t tiles = (PP ? 3 : 2 * SPB) * (2 * (size_t)BM * CV_ROW + 2 * (size_t)(NF * 16) * CV_ROW);
+    const size_t stage = (size_t)(NT / 64) * 16 * ((NF / WN) * 16 + 4) * 4;
     return tiles > stage ? tiles : stage;
 }
 
-template <int NF, int WN, int BM, int SPB, int TAIL = 0>
+template <int NF, int WN, int BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false>
 static hipError_t launch_conv_nf(const ConvParams& p, hipStream_t s) {
-    const dim3 grid((unsigned)((p.rows + BM - 1) / BM), (unsigned)(p.cout_pad / (NF * 16))), block(256);
-    const size_t lds = conv_lds_bytes<NF, WN, BM, SPB>();
+    const dim3 grid((unsigned)((p.rows + BM - 1) / BM), (unsigned)(p.cout_pad / (NF * 16))), block(NT);
+    const size_t lds = conv_lds_bytes<NF, WN, BM, SPB, NT, PP>();
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {          // > 64 KiB of dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB, TAIL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM, SPB, TAIL>), grid, block, lds, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
@@ -413,13 +485,21 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
     // Measured alternatives on the G-Net 3x3 layer (64 frames; this configuration: 2.31 ms): 64-row tile / 3 workgroups
     // per CU 2.80 ms; two K stages per barrier (4-stage ring, 128 KB LDS, 1 workgroup per CU) 3.51 ms; 256-row tile
     // (1 workgroup per CU) 3.45 ms.  The kernel lives on inter-workgroup overlap: keep 2 workgroups per CU.
+    const bool pp = (p.variant & 2) != 0;        // dev (MAGNET_CONV_VARIANT=2): the 8-wave ping-pong K loop — measured equal to the
+                                                 // default 4-wave / 2-slot loop (5.83 vs 5.91 ms per C2 step), so it is not the default
     if (p.tail_w_hi) {                           // 3x3 (or 1x1) 128-wide layer + its three 1x1 successors in one kernel
         if (p.cout_pad != 128) return hipErrorInvalidValue;
+        if (pp) {
+            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true>(p, s);
+            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true>(p, s);
+            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true>(p, s);
+        }
         if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 128, 1, 1>(p, s);
         if (p.tail_cout == 128) return launch_conv_nf<8, 2, 128, 1, 8>(p, s);
         if (p.tail_cout == 144) return launch_conv_nf<8, 2, 128, 1, 9>(p, s);
         return hipErrorInvalidValue;
     }
+    if (p.cout_pad % 128 == 0 && pp) return launch_conv_nf<8, 2, 256, 1, 0, 512, true>(p, s);
     if (p.cout_pad % 128 == 0) return launch_conv_nf<8, 2, 128, 1>(p, s);
     if (p.cout_pad == 144) return launch_conv_nf<9, 1, 128, 1>(p, s);
     if (p.cout_pad == 16)  return launch_conv_nf<1, 1, 128, 1>(p, s);

@@ -150,6 +150,9 @@ class MAGNET(nn.Module):
         # mask head on a side stream next to matcher + G-Net.  Measured on MI355X: no gain (10.15 vs 10.05 ms per C2 step) —
         # the workgroups of the two queues do not co-reside usefully; kept as an option, off by default.
         self.overlap_mask_head = False
+        # x_d3's NCHW fp32 -> split channel-last repack (HBM-bound, 0.6 ms per 64 C2 frames) on a side stream next to the first
+        # matcher launch (latency / VALU-bound): the two overlap almost completely
+        self.overlap_pack = False      # measured: 8.01 vs 8.08 ms per C2 step, and it stretches the matcher launch 1.06 -> 1.57 ms
         self._side = {}
         self.fuse_conv_tail = True     # 1x1 layers of g_net / mask_head fused into their 3x3 layer's epilogue
         self.fnet_mfma = True          # run a PSMNet-structured f_net on the matrix-core path (magnet_amd/fnet.py)
@@ -169,10 +172,33 @@ class MAGNET(nn.Module):
         return depth_sampling(self.sampling_range, self.n_samples)
 
     # -- the hot path proper: everything after the backbones --------------------------------------
+    def gnet_input_buffer(self, B, h, w, device):
+        """The split-bf16 zero-bordered channel-last buffer (B*(h+2)*(w+2), ctot) that holds [cost (D, padded to 8) | x_d3 (256)]
+        for the matrix-core G-Net / mask head: (hi, lo, ctot, c_off of x_d3).  A D-Net running on the matrix-core path writes
+        its x_d3 output into channels [c_off, c_off+256) of the interior rows and calls match_and_refine(x_d3_in_place=True):
+        no NCHW tensor, no repack pass."""
+        D = self.n_samples
+        Dp = (D + 7) // 8 * 8
+        if self._stacks is None:
+            self._stacks = (ConvStackMFMA(self.g_net.gnet, in_map=[(0, D, 0), (D, 256, Dp)]),
+                            ConvStackMFMA(self.mask_head))
+        ctot = self._stacks[0].cin_pad()
+        rows = B * (h + 2) * (w + 2)
+        wkey = (str(device), B, h, w, ctot)
+        work = self._work.get(wkey)
+        if work is None:
+            self._work.clear()                       # one shape at a time: the buffers are large
+            work = self._work[wkey] = {
+                "gin": (torch.zeros((rows, ctot), dtype=torch.bfloat16, device=device),   # zero border / zero pad
+                        torch.zeros((rows, ctot), dtype=torch.bfloat16, device=device)),  # channels stay zero
+                "cost": torch.empty((B, D, h, w), dtype=torch.float32, device=device)}
+        return work["gin"][0], work["gin"][1], ctot, Dp
+
     def match_and_refine(self, ref_gmms, x_d3, ref_feat_4, nghbr_feat_4, nghbr_gmms, nghbr_poses,
-                         is_valid, cam_intrins, mode="test", packed_feats=None):
+                         is_valid, cam_intrins, mode="test", packed_feats=None, x_d3_in_place=False):
         """MAGNET.py:146-175 from backbone outputs.  Returns the list of upsampled (B,2,H,W).
-        packed_feats: (ref_cl, src_pad) straight from the matrix-core F-Net instead of NCHW feature tensors."""
+        packed_feats: (ref_cl, src_pad) straight from the matrix-core F-Net instead of NCHW feature tensors.
+        x_d3_in_place: x_d3 already sits in gnet_input_buffer() (x_d3 may then be None)."""
         thres = int(self.weighting.split("CW")[1])
         matcher = CostVolumeCW(ref_feat_4, nghbr_feat_4, nghbr_gmms, nghbr_poses, is_valid, cam_intrins,
                                thres, feat_dtype=self.feat_dtype, path=self.matcher_path, packed=packed_feats)
@@ -180,8 +206,10 @@ class MAGNET(nn.Module):
         n_iter = self.train_iter if mode == "train" else self.test_iter
         training = torch.is_grad_enabled() and any(p.requires_grad for p in
                                                    list(self.g_net.parameters()) + list(self.mask_head.parameters()))
-        if self.conv_backend == "mfma" and not training and self.downsample_ratio == 4 and x_d3.shape[1] == 256:
-            return self._refine_mfma(matcher, ref_gmms, x_d3, n_iter)
+        if self.conv_backend == "mfma" and not training and self.downsample_ratio == 4 and (x_d3_in_place or x_d3.shape[1] == 256):
+            return self._refine_mfma(matcher, ref_gmms, None if x_d3_in_place else x_d3, n_iter)
+        if x_d3_in_place:
+            raise lib.MagnetError("x_d3_in_place needs the matrix-core convolution path (conv_backend='mfma', inference)")
 
         # ---- torch (MIOpen) convolutions: training, or conv_backend='torch' ----
         # G-Net input buffer: cost volume first, then x_d3 (MAGNET.py:167); x_d3 is copied once
@@ -206,38 +234,32 @@ class MAGNET(nn.Module):
         are re-packed per iteration (replaces torch.cat, MAGNET.py:167)."""
         B, _, h, w = ref_gmms.shape
         D = self.n_samples
-        Dp = (D + 7) // 8 * 8
-        dev = x_d3.device
-        if self._stacks is None:
-            self._stacks = (ConvStackMFMA(self.g_net.gnet, in_map=[(0, D, 0), (D, 256, Dp)]),
-                            ConvStackMFMA(self.mask_head))
+        dev = ref_gmms.device
+        gin_hi, gin_lo, ctot, Dp = self.gnet_input_buffer(B, h, w, dev)
         g_stack, m_stack = self._stacks
         g_stack.fuse_epilogue = m_stack.fuse_epilogue = self.fuse_conv_tail
-        ctot = g_stack.cin_pad()
         rows, wp = B * (h + 2) * (w + 2), w + 2
-        wkey = (str(dev), B, h, w, ctot)
-        work = self._work.get(wkey)
-        if work is None:
-            self._work.clear()                       # one shape at a time: the buffers are large
-            work = self._work[wkey] = {
-                "gin": (torch.zeros((rows, ctot), dtype=torch.bfloat16, device=dev),      # zero border / zero pad
-                        torch.zeros((rows, ctot), dtype=torch.bfloat16, device=dev)),     # channels stay zero
-                "cost": torch.empty((B, D, h, w), dtype=torch.float32, device=dev)}
-        gin_hi, gin_lo = work["gin"]
-        x_d3 = x_d3.detach().float().contiguous()
-        # The mask head depends on x_d3 only.  It is MFMA-bound while the matcher is VALU/latency-bound and the packs are
-        # HBM-bound, so it runs on a side stream next to [matcher -> G-Net]: pack(x_d3) -> mask head || matcher, with
-        # events where the chains meet (G-Net reads the packed x_d3; the upsampling reads the mask).
+        work = self._work[(str(dev), B, h, w, ctot)]
+        # Streams.  x_d3's repack (HBM-bound) runs on a side stream beside the first matcher launch (latency / VALU-bound);
+        # the mask head depends on x_d3 only and may run there too (overlap_mask_head: measured no gain — two matrix-core
+        # kernels do not co-reside usefully).  Events mark where the chains meet.
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev) if self.overlap_mask_head else main
-        if side is not main:
-            side.wait_stream(main)                   # x_d3 is ready; the previous forward no longer reads `gin`
-            x_d3.record_stream(side)
-        with torch.cuda.stream(side):
-            lib.pack_split(x_d3, gin_hi, gin_lo, ctot, Dp)
-            ev_pack = torch.cuda.Event(); ev_pack.record(side)
-            mask_pad, mask_ld = m_stack.run(gin_hi[:, Dp:], gin_lo[:, Dp:], ctot, rows, wp, work.setdefault("mask", {}))  # MAGNET.py:172
-            ev_mask = torch.cuda.Event(); ev_mask.record(side)
+        pack_stream = self._side_stream(dev) if (self.overlap_pack and x_d3 is not None) or self.overlap_mask_head else main
+        ev_pack = torch.cuda.Event()
+        if pack_stream is not main:
+            pack_stream.wait_stream(main)            # the packed features exist; the previous forward no longer reads `gin`
+        if x_d3 is not None:
+            x_d3 = x_d3.detach().float().contiguous()
+            if pack_stream is not main:
+                x_d3.record_stream(pack_stream)
+            with torch.cuda.stream(pack_stream):
+                lib.pack_split(x_d3, gin_hi, gin_lo, ctot, Dp)
+        ev_pack.record(pack_stream)
+        mask_out = None
+        if self.overlap_mask_head:
+            with torch.cuda.stream(pack_stream):
+                mask_out = m_stack.run(gin_hi[:, Dp:], gin_lo[:, Dp:], ctot, rows, wp, work.setdefault("mask", {}))  # MAGNET.py:172
+                ev_mask = torch.cuda.Event(); ev_mask.record(pack_stream)
         pred_list = [ref_gmms.detach().float().contiguous()]
         # With more than one refinement iteration the x_d3 part of G-Net's first layer (256 of the 256+D input
         # channels) is loop-invariant: compute W_x * x_d3 once, add it in the epilogue of the per-iteration
@@ -249,17 +271,26 @@ class MAGNET(nn.Module):
             gin_hi[:, :Dp].zero_(); gin_lo[:, :Dp].zero_()
             main.wait_event(ev_pack)
             partial = g_stack.run_invariant(gin_hi, gin_lo, ctot, rows, wp, work, Dp)
+        split_out = self.matcher_path in (0, 2, 4)
         for _ in range(n_iter):
-            if self.matcher_path in (0, 2, 4):
-                # the candidate-lane kernel writes the D cost channels of the G-Net input buffer directly
-                matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out_split=(gin_hi, gin_lo, ctot))  # MAGNET.py:153-164
-            else:
+            if split_out:
+                # the candidate-lane kernels write the D cost channels of the G-Net input buffer directly
+                try:
+                    matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out_split=(gin_hi, gin_lo, ctot))  # MAGNET.py:153-164
+                except lib.MagnetError:
+                    split_out = False                # a shape only the generic kernel takes (V >= 26, very wide F): NCHW + repack
+            if not split_out:
                 matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out=work["cost"])
                 lib.pack_split(work["cost"], gin_hi, gin_lo, ctot, 0)
             main.wait_event(ev_pack)                                                                 # x_d3 channels are in place
             g_out, g_ld = g_stack.run(gin_hi, gin_lo, ctot, rows, wp, work, first_addend=partial, n_var=Dp)  # MAGNET.py:62
             pred_list.append(lib.gaussian_update_cl(g_out, g_ld, pred_list[-1], h, w))               # MAGNET.py:60-69
-        main.wait_event(ev_mask)
+        if mask_out is None:
+            main.wait_event(ev_pack)
+            mask_out = m_stack.run(gin_hi[:, Dp:], gin_lo[:, Dp:], ctot, rows, wp, work.setdefault("mask", {}))      # MAGNET.py:172
+        else:
+            main.wait_event(ev_mask)
+        mask_pad, mask_ld = mask_out
         return [lib.upsample_depth_cl(pred, mask_pad, mask_ld) for pred in pred_list[1:]]            # MAGNET.py:173
 
     def forward(self, ref_img, nghbr_imgs, nghbr_poses, is_valid, cam_intrins, mode="train"):

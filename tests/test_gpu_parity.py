@@ -442,3 +442,32 @@ def test_full_step_bench_size_batch_invariance(hip_lib, gpu):
             one = model.match_and_refine(sel(inp["ref_gmms"]), sel(x_d3), sel(inp["ref_feat"]), nb, ng, sel(inp["nghbr_poses"]),
                                          sel(inp["is_valid"]), {kk: sel(v) for kk, v in inp["cam_intrins"].items()}, mode="test")[-1]
         assert torch.isfinite(one).all() and torch.equal(one[0], full[b]), f"frame {b}"
+
+
+def test_refine_with_inputs_in_kernel_layouts(hip_lib, gpu):
+    """match_and_refine fed features already in the matcher's layouts and x_d3 already in the G-Net input buffer (what
+    backbones on the matrix-core path hand over) returns exactly what the NCHW-input call returns; with and without the
+    side-stream repack."""
+    from magnet_amd import lib
+    from magnet_amd.magnet import MAGNET
+    wl = synth.Workload("pk", "scannet", 24, 32, V=2, D=64, F=64)
+    inp = synth.make_inputs(wl, B=2, seed=2)
+    d = to_dev(inp, gpu)
+    x_d3 = torch.randn(2, 256, wl.h, wl.w, generator=torch.Generator().manual_seed(3)).to(gpu) * 0.5
+    m = MAGNET(make_args(D=wl.D, iters=2, dpv_h=wl.h, dpv_w=wl.w), d_net=StubDNet(1), f_net=StubFNet(2), feat_dtype="bf16")
+    seeded_magnet_weights(m, 5)
+    m = m.to(gpu).eval()
+    outs = []
+    with torch.no_grad():
+        for overlap in (True, False):
+            m.overlap_pack = overlap
+            outs.append(m.match_and_refine(d["ref_gmms"], x_d3, d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"],
+                                           d["is_valid"], d["cam_intrins"], mode="test"))
+        packed = (lib.pack_features(d["ref_feat"], lib.feat_enum("bf16"), pad=0), lib.pack_features(d["nghbr_feat"], lib.feat_enum("bf16"), pad=1))
+        gh, gl, ctot, coff = m.gnet_input_buffer(2, wl.h, wl.w, gpu)
+        lib.pack_split(x_d3, gh, gl, ctot, coff)
+        outs.append(m.match_and_refine(d["ref_gmms"], None, None, None, d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"],
+                                       d["cam_intrins"], mode="test", packed_feats=packed, x_d3_in_place=True))
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert len(o) == 2 and all(torch.equal(a, b) for a, b in zip(o, outs[0]))
