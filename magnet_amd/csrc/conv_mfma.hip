@@ -124,7 +124,11 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
 // ahead, the other owns the matrix pipe — over a 3-slot LDS ring with counted vmcnt waits and raw s_barriers (no DMA drain at a
 // barrier).  The 4-wave / 2-slot loop (PP = false) drains the DMA queue (vmcnt(0)) at every step's __syncthreads and relies on a
 // second workgroup per CU to fill the gap: 41 % of the matrix pipe; see DESIGN.md §4.3.
-template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false>
+// WIN = row-window K loop: the taps of one tap ROW (ty fixed, tx = 0..tap_n-1) read the same activation rows shifted by tap_sx, so
+// their A operand is staged ONCE per (K chunk, ty) as a window of CV_BM + (tap_n-1)*tap_sx rows and the tx sub-steps read their
+// fragments at a row offset; only the weight tile changes per sub-step.  L2 requests per 3x3 tap row: 272 + 3*256 instead of
+// 3*(256 + 256) (counters: the kernel is L2-request-bound, TCC ~82 % busy, profiles/r2/pmc_conv_*.txt).
+template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, bool WIN = false>
 __global__ __launch_bounds__(NT) void conv_mfma_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins do not exist in the host pass (which only needs the stub)
     constexpr int BN = NF * 16;
@@ -134,7 +138,8 @@ __global__ __launch_bounds__(NT) void conv_mfma_kernel(const ConvParams p) {
     constexpr int MF = CV_BM / (WM * 16);             // M fragments per wave (2 or 4)
     constexpr int NFW = NF / WN;                      // N fragments per wave
     static_assert(NF % WN == 0, "N fragments must split evenly over the waves");
-    constexpr int A_BYTES = CV_BM * CV_ROW, B_BYTES = BN * CV_ROW;
+    constexpr int AW_ROWS = WIN ? CV_BM + 8 : CV_BM;           // window: up to (3-1)*2 extra rows (dilation 2), padded to 8
+    constexpr int A_BYTES = AW_ROWS * CV_ROW, B_BYTES = BN * CV_ROW;
     constexpr int STAGE_BYTES = 2 * A_BYTES + 2 * B_BYTES;    // hi + lo planes of A and B
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // ring of 2*SPB stages
 
@@ -251,6 +256,87 @@ __global__ __launch_bounds__(NT) void conv_mfma_kernel(const ConvParams p) {
         }
     };
 
+    if constexpr (WIN) {
+        static_assert(!PP && SPB == 1, "row-window loop: 2-slot ring");
+        // LDS: [A window slot 0 | A window slot 1 | B slot 0 | B slot 1], each hi + lo
+        unsigned char* const a_ring = smem;
+        unsigned char* const b_ring = smem + 2 * (2 * A_BYTES);
+        const int aw = CV_BM + (p.tap_n - 1) * p.tap_sx;      // window rows of this layer
+        const int ngroups = p.tap_n * ksteps_per_tap;         // (K chunk, ty) pairs, ty inner
+        int g_ty = 0, g_k0 = 0;                               // next window to fetch
+        int bs_tap = 0, bs_k0 = 0;                            // next weight tile to fetch: tap = ty*tap_n + tx, K chunk
+        auto dma_a = [&](int slot) {
+            unsigned char* sa_hi = a_ring + slot * (2 * A_BYTES);
+            unsigned char* sa_lo = sa_hi + A_BYTES;
+            const int a_u = (((g_ty + p.tap_o0) * p.tap_sy + p.tap_o0 * p.tap_sx) * p.in_ld + g_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < A_PT; ++i) {
+                CV_BLDS(ra_hi, sa_hi + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+                CV_BLDS(ra_lo, sa_lo + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+            }
+            if (wv == 0 && st_r < aw - CV_BM) {               // the (tap_n-1)*tap_sx rows past the tile: a few lanes of wave 0
+                const int ax = a_v[0] + CV_BM * p.in_ld * 2;
+                CV_BLDS(ra_hi, sa_hi + CV_BM * CV_ROW, ax + a_u);
+                CV_BLDS(ra_lo, sa_lo + CV_BM * CV_ROW, ax + a_u);
+            }
+            if (++g_ty == p.tap_n) { g_ty = 0; g_k0 += CV_BK; }
+        };
+        auto dma_b = [&](int slot) {
+            unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
+            unsigned char* sb_lo = sb_hi + B_BYTES;
+            const int b_u = (bs_tap * p.cout_pad * p.cin + bs_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < B_PT; ++i) {
+                if (st_r + i * RP < BN) {
+                    CV_BLDS(rb_hi, sb_hi + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+                    CV_BLDS(rb_lo, sb_lo + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+                }
+            }
+            if (++bs_tap == p.taps) { bs_tap = 0; bs_k0 += CV_BK; }
+        };
+        // fragment rows shifted by tx*tap_sx: the swizzle term follows the ACTUAL LDS row, so one offset per tx
+        int a_offx[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) a_offx[tx] = cv_swz(wm * (MF * 16) + frow + tx * p.tap_sx, lane >> 4);
+        auto compute_w = [&](int aslot, int bslot, int a_of) {
+            const unsigned char* sa_hi = a_ring + aslot * (2 * A_BYTES);
+            const unsigned char* sa_lo = sa_hi + A_BYTES;
+            const unsigned char* sb_hi = b_ring + bslot * (2 * B_BYTES);
+            const unsigned char* sb_lo = sb_hi + B_BYTES;
+            bf16x8_t ah[MF], al[MF];
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                ah[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa_hi + a_of + m * 16 * CV_ROW));
+                al[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa_lo + a_of + m * 16 * CV_ROW));
+            }
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+                const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
+                const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_lo + b_off + n * 16 * CV_ROW));
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh, acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
+            }
+        };
+        dma_a(0);
+        dma_b(0);
+        __syncthreads();
+        int bslot = 0;
+        for (int g = 0; g < ngroups; ++g) {
+            const int aslot = g & 1;
+            for (int tx = 0; tx < p.tap_n; ++tx) {
+                const bool last_tx = tx + 1 == p.tap_n;
+                if (!(last_tx && g + 1 == ngroups)) dma_b(bslot ^ 1);              // next sub-step's weights
+                if (last_tx && g + 1 < ngroups) dma_a(aslot ^ 1);                  // next group's window
+                compute_w(aslot, bslot, tx == 0 ? a_offx[0] : (tx == 1 ? a_offx[1] : a_offx[2]));
+                __syncthreads();
+                bslot ^= 1;
+            }
+        }
+    } else
     if constexpr (PP) {
         static_assert(NT == 512 && BN % RP == 0 && CV_BM % RP == 0 && A_PT + B_PT <= NFW, "ping-pong loop: 8 waves, whole DMA passes, one DMA pass per N fragment");
         constexpr int GL = 2 * A_PT + 2 * B_PT;               // LDS-DMA instructions per wave and stage
@@ -459,24 +545,25 @@ __global__ __launch_bounds__(NT) void conv_mfma_kernel(const ConvParams p) {
 #endif
 }
 
-template <int NF, int WN, int BM, int SPB, int NT = 256, bool PP = false>
+template <int NF, int WN, int BM, int SPB, int NT = 256, bool PP = false, bool WIN = false>
 static size_t conv_lds_bytes() {
-    const size_t tiles = (PP ? 3 : 2 * SPB) * (2 * (size_t)BM * CV_ROW + 2 * (size_t)(NF * 16) * CV_ROW);
+    const size_t tiles = (PP ? 3 : 2 * SPB) * (2 * (size_t)(WIN ? BM + 8 : BM) * CV_ROW + 2 * (size_t)(NF * 16) * CV_ROW);
     const size_t stage = (size_t)(NT / 64) * 16 * ((NF / WN) * 16 + 4) * 4;
     return tiles > stage ? tiles : stage;
 }
 
-template <int NF, int WN, int BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false>
+template <int NF, int WN, int BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, bool WIN = false>
 static hipError_t launch_conv_nf(const ConvParams& p, hipStream_t s) {
     const dim3 grid((unsigned)((p.rows + BM - 1) / BM), (unsigned)(p.cout_pad / (NF * 16))), block(NT);
-    const size_t lds = conv_lds_bytes<NF, WN, BM, SPB, NT, PP>();
+    size_t lds = conv_lds_bytes<NF, WN, BM, SPB, NT, PP, WIN>();
+    if (TAIL > 0 && lds < (size_t)BM * 512) lds = (size_t)BM * 512;     // the fused tail's activation tile: BM rows x 256 B x (hi, lo)
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {          // > 64 KiB of dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP, WIN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP>), grid, block, lds, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP, WIN>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
@@ -494,11 +581,23 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
             if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true>(p, s);
             if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true>(p, s);
         }
+        const bool win = p.tap_n > 1 && !(p.variant & 1);       // dev (MAGNET_CONV_VARIANT=1): one A stage per tap
+        if (win && (p.variant & 4)) {                           // dev (MAGNET_CONV_VARIANT=4): 256-row tile, 8 waves, one workgroup per CU
+            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, false, true>(p, s);
+            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, false, true>(p, s);
+            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, false, true>(p, s);
+        }
+        if (win) {
+            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 128, 1, 1, 256, false, true>(p, s);
+            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 128, 1, 8, 256, false, true>(p, s);
+            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 128, 1, 9, 256, false, true>(p, s);
+        }
         if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 128, 1, 1>(p, s);
         if (p.tail_cout == 128) return launch_conv_nf<8, 2, 128, 1, 8>(p, s);
         if (p.tail_cout == 144) return launch_conv_nf<8, 2, 128, 1, 9>(p, s);
         return hipErrorInvalidValue;
     }
+    if (p.cout_pad % 128 == 0 && p.tap_n > 1 && !(p.variant & 1) && !pp) return launch_conv_nf<8, 2, 128, 1, 0, 256, false, true>(p, s);
     if (p.cout_pad % 128 == 0 && pp) return launch_conv_nf<8, 2, 256, 1, 0, 512, true>(p, s);
     if (p.cout_pad % 128 == 0) return launch_conv_nf<8, 2, 128, 1>(p, s);
     if (p.cout_pad == 144) return launch_conv_nf<9, 1, 128, 1>(p, s);
