@@ -36,6 +36,12 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# Per-file flags.  The matcher kernels are VALU-issue-bound; clang's SLP vectoriser packs adjacent fp32 mul/add/fma into
+# v_pk_*_f32, which on gfx950 run at HALF the per-instruction rate of their scalar forms (tools/ubench/valu_rate.hip: 4.9 vs
+# 2.5 cycles) and need their operands copied into aligned register pairs (55 v_mov per 4 views): packing is a net loss there.
+EXTRA_FLAGS = {"cost_volume_fast.hip": ["-fno-slp-vectorize"], "cost_volume_fast64.hip": ["-fno-slp-vectorize"]}
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
@@ -43,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc(), *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc(), *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                     const uint32_t tkey = inwin ? qi : FKEY_CLOSED;
                     const uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);
                     const bool lead = inwin && (tkey != tprev);
-                    const unsigned long long lbal = __ballot(lead);
+                    const unsigned long long lbal = __builtin_amdgcn_ballot_w64(lead);
                     const int run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lbal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lbal, lead ? 1u : 0u));
                     if (lead) {
                         gslot[run * 2 + 0] = *reinterpret_cast<const float4*>(sgm + qi * 8u);
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                 uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)key, 0x138, 0xf, 0xf, false);  // wave_shr:1
                 if (PPW > 1 && j0 == 0) prev = FKEY_CLOSED;                       // first candidate of a pixel group
                 const bool fresh = gate && (key != prev);
-                const unsigned long long bal = __ballot(fresh);
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(fresh);
                 if (bal == 0ull) continue;                                        // wave-uniform: nothing open in this view
                 const int nitems = __popcll(bal);
                 const int incl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),

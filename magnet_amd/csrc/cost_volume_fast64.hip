@@ -13,6 +13,7 @@
 // VG bilinear combines run: two memory round trips per GROUP instead of two per view.
 //
 // Arithmetic, tolerance contract, layouts: exactly cost_volume_fast.hip (see its header).
+#include <stdlib.h>
 #include "cv_fast_common.hpp"
 
 namespace magnet {
@@ -186,8 +187,9 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
                         const float ax = 1.0f - bx, ay = 1.0f - by;
                         wnw[u] = ax * ay; wne[u] = bx * ay; wsw[u] = ax * by; wse[u] = bx * by;   // homography.py:150-152
                         inwin[u] = (__float_as_uint(ixs) < xlim) && (__float_as_uint(iys) < ylim);
-                        const int xq = (int)__builtin_amdgcn_fmed3f(x0f, 0.0f, fwc), yq = (int)__builtin_amdgcn_fmed3f(y0f, 0.0f, fhc);
-                        qi[u] = (uint32_t)__mul24(yq, Wp) + (uint32_t)xq;        // quad origin in the padded map (exact when inwin)
+                        // v_cvt_u32_f32 saturates: negative / NaN -> 0; then an unsigned min against the map size
+                        const uint32_t xq = min((uint32_t)x0f, (uint32_t)p.w), yq = min((uint32_t)y0f, (uint32_t)p.h);
+                        qi[u] = __umul24(yq, (uint32_t)Wp) + xq;                 // quad origin in the padded map (exact when inwin)
                         const unsigned char* __restrict__ sgm = sgm_b + (size_t)vv * sgm_vstride;
                         if (!LEAD) {
                             g0[u] = *reinterpret_cast<const float4*>(sgm + qi[u] * 8u);             // (mu,sg) x0, x0+1 of row y0
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
                             const uint32_t tkey = inwin[u] ? qi[u] : FKEY_CLOSED;
                             const uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);
                             const bool lead = inwin[u] && (tkey != tprev);
-                            const unsigned long long lbal = __ballot(lead);
+                            const unsigned long long lbal = __builtin_amdgcn_ballot_w64(lead);
                             run[u] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lbal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lbal, lead ? 1u : 0u));
                             if (lead) {
                                 gslot[(u * 65 + run[u]) * 2 + 0] = *reinterpret_cast<const float4*>(sgm + qi[u] * 8u);
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
                     const uint32_t key = gate[u] ? qi[u] : FKEY_CLOSED;
                     const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)key, 0x138, 0xf, 0xf, false);  // wave_shr:1
                     fresh[u] = gate[u] && (key != prev);
-                    const unsigned long long bal = __ballot(fresh[u]);
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(fresh[u]);
                     cnt[u] = __popcll(bal);
                     incl[u] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
                                    __builtin_amdgcn_mbcnt_lo((uint32_t)bal, fresh[u] ? 1u : 0u));  // view's items at or below this lane
@@ -370,7 +372,13 @@ hipError_t launch_cv_fast64(const CvParams& p, hipStream_t stream, bool* handled
     const int nchunk = (int)(p.F * esz / 16);
     *handled = true;
     if (p.feat_bf16) {
-        if (nchunk == 8)  return launch_fast64<uint16_t, 2, true, 5, 4>(p, stream);       // F = 64: 4 lanes x 32 B per (item, tap) unit
+        if (nchunk == 8) {                                                                 // F = 64: 4 lanes x 32 B per (item, tap) unit
+            static const int dev_minw = getenv("MAGNET_MATCH_MINW") ? atoi(getenv("MAGNET_MATCH_MINW")) : 0;   // dev: occupancy A/B
+            if (dev_minw == 4) return launch_fast64<uint16_t, 2, true, 4, 4>(p, stream);
+            if (dev_minw == 6) return launch_fast64<uint16_t, 2, true, 6, 4>(p, stream);
+            if (dev_minw == 8) return launch_fast64<uint16_t, 2, true, 8, 4>(p, stream);
+            return launch_fast64<uint16_t, 2, true, 5, 4>(p, stream);
+        }
         if (nchunk <= 8)  return launch_fast64<uint16_t, 1, false, 5, 8>(p, stream);
         if (nchunk <= 16) return launch_fast64<uint16_t, 2, false, 5, 8>(p, stream);
     } else {
