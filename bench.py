@@ -291,6 +291,27 @@ def main():
         sus_elapsed = mdist.max_over_ranks(time.perf_counter() - t_s, device=device)
         sustained = world * B * n_sus / sus_elapsed
 
+    # the same step when the backbones hand their outputs over in the kernels' layouts (what magnet_amd/fnet.py's F-Net does):
+    # no pack pass.  Reported next to the contract number, never instead of it.
+    packed_ms = None
+    if not (a.kernel_only or a.graph or a.packed_inputs) and a.conv_backend == "mfma":
+        packed = (lib.pack_features(inp["ref_feat"], lib.feat_enum(fdt), pad=0), lib.pack_features(inp["nghbr_feat"], lib.feat_enum(fdt), pad=1))
+        gh, gl, ctot, coff = model.gnet_input_buffer(B, wl.h, wl.w, device)
+        lib.pack_split(inp["x_d3"], gh, gl, ctot, coff)
+        CostVolumeCW.event_sink = None; ConvStackMFMA.event_sink = None
+
+        def pstep():
+            with torch.no_grad():
+                model.match_and_refine(inp["ref_gmms"], None, None, None, inp["nghbr_gmms"], inp["nghbr_poses"], inp["is_valid"],
+                                       inp["cam_intrins"], mode="test", packed_feats=packed, x_d3_in_place=True)
+        for _ in range(3):
+            pstep()
+        torch.cuda.synchronize(); t_p = time.perf_counter()
+        for _ in range(a.steps):
+            pstep()
+        torch.cuda.synchronize()
+        packed_ms = mdist.max_over_ranks(1e3 * (time.perf_counter() - t_p) / a.steps, device=device)
+
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev_pairs) / max(1, len(ev_pairs))
     # HBM traffic of the fused kernel comes from separate rocprofv3 --pmc passes (tools/profile_round.sh),
     # committed under profiles/; bench.py cannot collect counters itself, so it quotes that record
@@ -341,6 +362,8 @@ def main():
                          "launches_timed": len(ev_pairs)},
             "cost_volume_frames_per_s": B / (kern_ms * 1e-3) if kern_ms > 0 else None,
             "sustained_frames_per_s": sustained,
+            "ms_per_step_inputs_in_kernel_layouts": packed_ms,
+            "frames_per_s_inputs_in_kernel_layouts": (world * B / (packed_ms * 1e-3)) if packed_ms else None,
             "weight_broadcast_bytes": bcast_bytes,
         }
         if pmc:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) into the committed profiles/<tag>/ records:
-bench line, rocprofv3 kernel stats, the PMC rows of our kernels and traffic_C2.json (FETCH_SIZE x calibration + WRITE_SIZE)."""
+bench line, rocprofv3 kernel stats, the counter rows of our kernels, traffic_C2.json (FETCH_SIZE / WRITE_SIZE corrected by the
+calibration copy of the same session) with the matcher's SQ counters, kernel-only lines of every config, extra runs."""
 import collections
 import csv
 import glob
@@ -10,56 +11,75 @@ import shutil
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 src, dst = os.path.join(R, "gpurun_out", tag), os.path.join(R, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
 
-def agg(pat):
-    d = collections.defaultdict(list)
+def rows_of(pat):
     for f in glob.glob(pat, recursive=True):
-        for r in csv.DictReader(open(f)):
-            d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return d
+        yield from csv.DictReader(open(f))
 
 
-fe, wr, ca = (agg(os.path.join(src, s, "**", "*counter_collection.csv")) for s in ("fetch", "write", "calib"))
-calib = [v for k, v in ca.items() if "copyBuffer" in k][0]
-calib_kb = sum(calib) / len(calib)
-corr = (1 << 20) / calib_kb                      # the calibration copy reads 1 GiB = 2^20 KiB
+# ---- counters per kernel (mean over dispatches) ----
+ctr = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+for r in rows_of(os.path.join(src, "pmc*", "**", "*counter_collection.csv")):
+    k = r["Kernel_Name"].split("(")[0]
+    if "magnet::" not in k:
+        continue
+    ctr[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+calib = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    v = [float(r["Counter_Value"]) for r in rows_of(os.path.join(src, f"calib_{c}", "**", "*counter_collection.csv"))
+         if "copy" in r["Kernel_Name"].lower() and r["Counter_Name"] == c]
+    calib[c] = sum(v) / len(v) if v else None
+GiB_KB = float(1 << 20)
+fcorr = GiB_KB / calib["FETCH_SIZE"] if calib["FETCH_SIZE"] else 2.0
+wcorr = GiB_KB / calib["WRITE_SIZE"] if calib["WRITE_SIZE"] else 1.0
+with open(os.path.join(dst, "pmc_kernels.txt"), "w") as o:
+    o.write(f"# mean per dispatch over the rocprofv3 --pmc passes of `python bench.py --steps 3 --warmup 1` (tools/profile_round.sh)\n"
+            f"# calibration copy (1 GiB read + 1 GiB write): FETCH_SIZE {calib['FETCH_SIZE']} KB, WRITE_SIZE {calib['WRITE_SIZE']} KB"
+            f" -> corrections x{fcorr:.3f}, x{wcorr:.3f}\n")
+    for k, d in sorted(ctr.items()):
+        o.write(f"KERNEL {k}   mean dispatch {sum(dur[k]) / len(dur[k]) / 1e3:.1f} us (profiled)\n")
+        for c, v in sorted(d.items()):
+            o.write(f"  {c:36s} {sum(v) / len(v):18.1f}  n={len(v)}\n")
 
-
-def kern(sub):
-    f = [x for k, v in fe.items() if sub in k for x in v]
-    w = [x for k, v in wr.items() if sub in k for x in v]
-    return sum(f) / len(f), sum(w) / len(w), len(f)
-
-
-out = {"workload": "C2, 64 frames/launch, bf16 features", "calib_copy_1GiB_FETCH_SIZE_KB": calib_kb, "fetch_correction": corr, "kernels": {}}
-for name, sub, alg in (("cost_volume", "cv_cand_kernel", 1150156800), ("conv_gnet_stack_fused", "conv_mfma_kernel<8, 2, 128, 1, 1>", None),
-                       ("conv_mask_stack_fused", "conv_mfma_kernel<8, 2, 128, 1, 9>", None)):
-    f, w, n = kern(sub)
-    out["kernels"][name] = {"kernel": sub, "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB_raw": w, "fetch_bytes_corrected": f * 1024 * corr,
-                            "write_bytes": w * 1024, "traffic_bytes_per_launch": f * 1024 * corr + w * 1024,
-                            "algorithmic_bytes_per_launch": alg, "dispatches": n}
-cv = out["kernels"]["cost_volume"]
-out.update({"traffic_bytes_per_launch": cv["traffic_bytes_per_launch"], "algorithmic_bytes_per_launch": 1150156800,
-            "kernel": [k for k in fe if "cv_cand_kernel" in k][0].split("(")[0] + " (split-bf16 channel-last cost output)",
-            "note": "FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes (tools/profile_round.sh); FETCH_SIZE corrected by the "
-                    "factor measured on a 1 GiB device copy in the same session (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md "
-                    "§HBM; Infinity-Cache hits are counted too); WRITE_SIZE uncalibrated."})
+mk = [k for k in ctr if "cv_fast64_kernel" in k or "cv_fast_kernel" in k]
+out = {"workload": "C2, 64 frames/launch, bf16 features, split-bf16 cost output (inside the bench step)",
+       "calib_copy_1GiB_KB": calib, "fetch_correction": fcorr, "write_correction": wcorr}
+if mk:
+    k = mk[0]
+    m = {c: sum(v) / len(v) for c, v in ctr[k].items()}
+    fetch, write = m.get("FETCH_SIZE", 0) * 1024 * fcorr, m.get("WRITE_SIZE", 0) * 1024 * wcorr
+    iters = 64 * 120 * 160 * 4                                     # (pixel, view) wave iterations per launch
+    us = sum(dur[k]) / len(dur[k]) / 1e3
+    out.update({"kernel": k.replace("void magnet::", ""), "traffic_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+                "algorithmic_bytes_per_launch": 1150156800,
+                "sq": {"valu_insts_per_pixel_view": m.get("SQ_INSTS_VALU", 0) / iters, "salu_insts_per_pixel_view": m.get("SQ_INSTS_SALU", 0) / iters,
+                       "vmem_insts_per_pixel_view": m.get("SQ_INSTS_VMEM_RD", 0) / iters, "lds_insts_per_pixel_view": m.get("SQ_INSTS_LDS", 0) / iters,
+                       "l1_accesses_per_pixel_view": m.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / iters,
+                       "valu_busy_frac": m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024 * us * 1e-6 * 2.4e9) if us else None,
+                       "wave_cycles_waiting_frac": m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
+                       "l2_hit_frac": m.get("TCC_HIT_sum", 0) / max(1.0, m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0)),
+                       "profiled_launch_us": us,
+                       "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x profiled duration x 2.4 GHz)"}})
 json.dump(out, open(os.path.join(dst, "traffic_C2.json"), "w"), indent=1)
+
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench_C2.json"))
-rows = list(csv.DictReader(open(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0])))
-with open(os.path.join(dst, "bench_C2_kernel_stats.csv"), "w") as o:
-    w = csv.writer(o); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-    for r in rows[:16]:
-        w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-for nm, s in (("pmc_FETCH_SIZE.csv", "fetch"), ("pmc_WRITE_SIZE.csv", "write"), ("pmc_calib_copy_FETCH_SIZE.csv", "calib")):
-    f = glob.glob(os.path.join(src, s, "**", "*counter_collection.csv"), recursive=True)[0]
-    with open(os.path.join(dst, nm), "w") as o:
-        w = csv.writer(o); w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value", "Dispatch_Id"])
-        for r in csv.DictReader(open(f)):
-            if any(t in r["Kernel_Name"] for t in ("magnet::", "copyBuffer")):
-                w.writerow([r["Kernel_Name"][:120], r["Counter_Name"], r["Counter_Value"], r["Dispatch_Id"]])
-print(json.dumps(cv, indent=1))
+st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    rows = list(csv.DictReader(open(st[0])))
+    with open(os.path.join(dst, "bench_C2_kernel_stats.csv"), "w") as o:
+        w = csv.writer(o); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows[:16]:
+            w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+for f in ("configs.jsonl", "ablate_C2_split.log", "ablate_C2_nchw.log", "valu_rate.txt"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f if f != "configs.jsonl" else "matcher_kernel_only_all_configs.jsonl"))
+os.makedirs(os.path.join(dst, "extra"), exist_ok=True)
+for f in glob.glob(os.path.join(src, "extra", "*.json")):
+    shutil.copy(f, os.path.join(dst, "extra", os.path.basename(f)))
+print(json.dumps(out, indent=1)[:3000])

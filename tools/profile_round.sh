@@ -1,35 +1,38 @@
 #!/bin/bash
-# GPU box: official bench line + rocprofv3 kernel stats + HBM traffic counters for the round.
-# usage: tools/profile_round.sh <round-tag>
-tag=${1:-r1}
+# GPU box: the round's official artefacts -> gpurun_out/<tag>/ (tools/collect_profile.py turns them into profiles/<tag>/):
+# bench line, rocprofv3 kernel stats, separate --pmc passes (FETCH_SIZE, WRITE_SIZE, two SQ sets) over the SAME command, the
+# FETCH/WRITE calibration on a 1 GiB device copy, kernel-only runs of every BASELINE config, extra step configurations.
+# Every profiler pass has a short timeout: some TA/TCP/TD counter sets hang rocprofv3 on this pool.
+tag=${1:-r2}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/$tag
-python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/stats -o s -- python bench.py --no-cpu-baseline > gpurun_out/$tag/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/$tag/fetch -o f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$tag/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/$tag/write -o w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$tag/write.log 2>&1
-# calibration of FETCH_SIZE on a known streaming read (a 1 GiB torch copy)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/$tag/calib -o c -- python -c "
+O=gpurun_out/$tag; mkdir -p $O
+python bench.py > $O/bench.json 2> $O/bench.err
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --no-cpu-baseline --sustain-s 0 > $O/stats.log 2>&1
+i=0
+for ctrs in "FETCH_SIZE" "WRITE_SIZE" \
+            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_MFMA" \
+            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA" \
+            "TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 90 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc$i -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --sustain-s 0 > $O/pmc$i.log 2>&1 || echo "pmc pass $i failed"
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+timeout 90 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/calib_$c -o c -- python -c "
 import torch
 x=torch.empty(1<<28,dtype=torch.float32,device='cuda'); y=torch.empty_like(x)
 for _ in range(3): y.copy_(x)
-torch.cuda.synchronize()" > gpurun_out/$tag/calib.log 2>&1
-python - <<PY
-import csv,glob,collections,json
-def agg(pattern, key):
-    d=collections.defaultdict(list)
-    for f in glob.glob(pattern, recursive=True):
-        for r in csv.DictReader(open(f)):
-            d[r["Kernel_Name"].split("(")[0][:70]].append(float(r[key]))
-    return d
-for name,pat in (("FETCH_SIZE","gpurun_out/$tag/fetch/**/*counter_collection.csv"),("WRITE_SIZE","gpurun_out/$tag/write/**/*counter_collection.csv"),("CALIB FETCH_SIZE","gpurun_out/$tag/calib/**/*counter_collection.csv")):
-    d=agg(pat,"Counter_Value")
-    print("==",name,"(KB per dispatch, mean)")
-    for k,v in sorted(d.items(), key=lambda kv:-sum(kv[1]))[:8]:
-        print(f"  {k:70s} {sum(v)/len(v):14.1f}  n={len(v)}")
-PY
-head -40 $(find gpurun_out/$tag/stats -name "*kernel_stats.csv" | head -1) | cut -c1-220
-tail -1 gpurun_out/$tag/bench.json
-find gpurun_out/$tag -name "*.db" -delete; find gpurun_out/$tag -name "*_agent_info.csv" -delete
-# keep traces small: drop the raw kernel trace of the stats run beyond the summary
-for f in $(find gpurun_out/$tag -name "*kernel_trace.csv"); do head -400 $f > $f.head; rm $f; done
+torch.cuda.synchronize()" > $O/calib_$c.log 2>&1
+done
+: > $O/configs.jsonl
+for wl in C1 C2 C4 C5 C2L C2Lf C4L shipped; do
+  timeout 120 python bench.py --kernel-only --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --sustain-s 0 2>/dev/null | tail -1 >> $O/configs.jsonl
+done
+mkdir -p $O/extra
+timeout 120 python bench.py --no-cpu-baseline --packed-inputs > $O/extra/bench_C2_packed_inputs.json 2>/dev/null
+for wl in C3 C4 C5 shipped; do timeout 120 python bench.py --no-cpu-baseline --workload $wl > $O/extra/bench_$wl.json 2>/dev/null; done
+timeout 100 python tools/ablate.py C2 64 split > $O/ablate_C2_split.log 2>&1
+timeout 100 python tools/ablate.py C2 64 > $O/ablate_C2_nchw.log 2>&1
+tools/ubench/valu_rate > $O/valu_rate.txt 2>&1
+find $O -name "*.db" -delete; find $O -name "*_agent_info.csv" -delete
+for f in $(find $O -name "*kernel_trace.csv"); do head -200 $f > $f.head; rm $f; done
+tail -1 $O/bench.json | cut -c1-400
