@@ -20,7 +20,7 @@ sys.path.insert(0, REPO)
 from magnet_amd import metrics as M  # noqa: E402
 from magnet_amd import synth  # noqa: E402
 from magnet_amd.magnet import MAGNET  # noqa: E402
-from magnet_amd.preprocess import data_preprocess  # noqa: E402
+from magnet_amd.preprocess import data_preprocess, data_preprocess_device  # noqa: E402,F401
 
 
 class SyntheticWindows:
@@ -57,12 +57,14 @@ def validate(model, args, test_loader, device):
         metrics = M.RunningAverageDict()
         for data_array, cam_intrins in test_loader:
             cur_batch_size = data_array[0]["img"].size()[0]
-            ref_dat, nghbr_dats, nghbr_poses, is_valid = data_preprocess(data_array, cur_batch_size)
+            # relative poses / validity on the device (float64 inverse there; they never come back to the host)
+            ref_dat, nghbr_dats, nghbr_poses, is_valid = data_preprocess_device(data_array, cur_batch_size, device)
             ref_img = ref_dat["img"].to(device)
             gt_dmap = ref_dat["gt_dmap"].to(device)
             nghbr_imgs = torch.cat([d["img"].to(device) for d in nghbr_dats], dim=0)       # view-major
-            pred_list = model(ref_img, nghbr_imgs, nghbr_poses.to(device), is_valid, cam_intrins, mode="test")
-            for m in M.compute_depth_errors(pred_list[-1], gt_dmap, args.min_depth, args.max_depth):
+            pred_list = model(ref_img, nghbr_imgs, nghbr_poses, is_valid, cam_intrins, mode="test")
+            crop = "garg" if getattr(args, "garg_crop", False) else ("eigen" if getattr(args, "eigen_crop", False) else None)
+            for m in M.compute_depth_errors(pred_list[-1], gt_dmap, args.min_depth, args.max_depth, crop=crop):   # test_MaGNet.py:58-79
                 metrics.update(m)
         return metrics.get_value()
 
@@ -79,6 +81,8 @@ def main():
     ap.add_argument("--window_radius", type=int, default=20)
     ap.add_argument("--dataset_format", default="scannet", choices=["scannet", "7scenes"],
                     help="folder layout; the split file has '<scene> <frame>' or '<scene> <sequence> <frame>' lines")
+    ap.add_argument("--garg_crop", action="store_true", help="KITTI: evaluate inside the Garg ECCV16 window (test_MaGNet.py:67-68)")
+    ap.add_argument("--eigen_crop", action="store_true", help="KITTI: evaluate inside the Eigen NIPS14 window (test_MaGNet.py:69-70)")
     ap.add_argument("--psmnet", action="store_true", help="use the PSMNet F-Net (matrix-core path) instead of the stub F-Net")
     a = ap.parse_args()
     from magnet_amd.standin import StubDNet, StubFNet, make_args, seeded_magnet_weights
@@ -87,6 +91,7 @@ def main():
     device = torch.device("cuda:0")
     args = make_args(D=a.D, iters=a.iters, dpv_h=a.input_height // 4, dpv_w=a.input_width // 4, V=a.V)
     args.min_depth, args.max_depth = a.min_depth, a.max_depth
+    args.garg_crop, args.eigen_crop = a.garg_crop, a.eigen_crop
     f_net = StubFNet(2)
     if a.psmnet:
         from magnet_amd.fnet import FNET

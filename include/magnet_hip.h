@@ -273,6 +273,11 @@ MAGNET_API int magnet_upsample_depth_cl(const float *depth, const float *mask_pa
  * (magnet_amd/metrics.py). */
 MAGNET_API int magnet_depth_metrics(const float *pred, const float *gt, double *sums, int32_t B, int32_t HW,
                                     float min_depth, float max_depth, void *stream);
+/* The same over the evaluation window rows [y0,y1) x columns [x0,x1) only: the reference's garg / eigen crops for KITTI
+ * (test_MaGNet.py:63-71).  Both entry points sum in a fixed order (one workgroup per frame): results are deterministic. */
+MAGNET_API int magnet_depth_metrics_crop(const float *pred, const float *gt, double *sums, int32_t B, int32_t H, int32_t W,
+                                         float min_depth, float max_depth, int32_t y0, int32_t y1, int32_t x0, int32_t x1,
+                                         void *stream);
 
 #ifdef __cplusplus
 }

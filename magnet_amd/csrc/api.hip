@@ -20,7 +20,7 @@ hipError_t launch_fnet_stem(const float*, const float*, const float*, uint16_t*,
 hipError_t launch_space_to_depth(const uint16_t*, const uint16_t*, uint16_t*, uint16_t*, int, int, int, int, int, hipStream_t);
 hipError_t launch_avgpool_cl(const uint16_t*, const uint16_t*, int, int, int, int, int, int, int, uint16_t*, uint16_t*, hipStream_t);
 hipError_t launch_upsample_bilinear_cl(const float*, int, int, int, int, uint16_t*, uint16_t*, int, int, int, int, int, hipStream_t);
-hipError_t launch_depth_metrics(const float*, const float*, double*, int, int, float, float, hipStream_t);
+hipError_t launch_depth_metrics(const float*, const float*, double*, int, int, int, float, float, int, int, int, int, hipStream_t);
 hipError_t launch_make_rays(const double*, float*, int, int, int, hipStream_t);
 hipError_t launch_relative_poses(const double*, const double*, float*, int32_t*, int, int, hipStream_t);
 }
@@ -379,8 +379,17 @@ MAGNET_API int magnet_depth_metrics(const float* pred, const float* gt, double* 
                                     float max_depth, void* stream) {
     if (!pred || !gt || !sums) return fail(MAGNET_E_NULL, "magnet_depth_metrics: NULL pointer");
     if (B <= 0 || HW <= 0 || !(max_depth > min_depth)) return fail(MAGNET_E_DIM, "magnet_depth_metrics: bad arguments");
-    hipError_t e = magnet::launch_depth_metrics(pred, gt, sums, B, HW, min_depth, max_depth, (hipStream_t)stream);
+    hipError_t e = magnet::launch_depth_metrics(pred, gt, sums, B, HW, HW, min_depth, max_depth, 0, -1, 0, 0, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_depth_metrics launch");
+}
+
+MAGNET_API int magnet_depth_metrics_crop(const float* pred, const float* gt, double* sums, int32_t B, int32_t H, int32_t W,
+                                         float min_depth, float max_depth, int32_t y0, int32_t y1, int32_t x0, int32_t x1, void* stream) {
+    if (!pred || !gt || !sums) return fail(MAGNET_E_NULL, "magnet_depth_metrics_crop: NULL pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || !(max_depth > min_depth) || y0 < 0 || x0 < 0 || y1 > H || x1 > W || y1 < y0 || x1 < x0)
+        return fail(MAGNET_E_DIM, "magnet_depth_metrics_crop: bad arguments");
+    hipError_t e = magnet::launch_depth_metrics(pred, gt, sums, B, H * W, W, min_depth, max_depth, y0, y1, x0, x1, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_depth_metrics_crop launch");
 }
 
 }  // extern "C"

@@ -203,19 +203,27 @@ hipError_t launch_upsample_cl(const float* d, const float* m, int ld, float* o, 
 // sums[b][0..15] = n, |d|, |d|/gt, d^2/gt, d^2, (ln gt - ln p)^2, (ln p - ln gt), |log10 gt - log10 p|,
 //                  (1/gt - 1/p)^2, [t<1.25], [t<1.25^2], [t<1.25^3], nll term, 0, 0, 0      with d = gt - p, t = max(gt/p, p/gt)
 constexpr int MET_N = 16;
-__global__ __launch_bounds__(256) void depth_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
-                                                             double* __restrict__ sums, int HW, float dmin, float dmax) {
-    const int b = blockIdx.y;
+// One workgroup of 1024 threads per frame, fixed summation order (per-thread strided sums -> wave shuffle tree -> 16 wave
+// partials added in order): results are run-to-run deterministic, no atomics, no memset.  Optional evaluation window
+// [cy0,cy1) x [cx0,cx1) = the reference's rectangular garg / eigen crops (test_MaGNet.py:63-71); cy1 < 0 = whole frame.
+__global__ __launch_bounds__(1024) void depth_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                              double* __restrict__ sums, int HW, int W, float dmin, float dmax,
+                                                              int cy0, int cy1, int cx0, int cx1) {
+    const int b = blockIdx.x;
     double acc[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) acc[i] = 0.0;
     const float* mu = pred + (size_t)b * 2 * HW;
     const float* sg = mu + HW;
     const float* g = gt + (size_t)b * HW;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    for (int i = threadIdx.x; i < HW; i += 1024) {
         float gv = g[i];
         if (gv > dmax) gv = 0.f;                                       // test_MaGNet.py:43
         if (!(gv > dmin && gv < dmax)) continue;                       // test_MaGNet.py:58
+        if (cy1 >= 0) {                                                // test_MaGNet.py:63-71
+            const int yy = i / W, xx = i - yy * W;
+            if (yy < cy0 || yy >= cy1 || xx < cx0 || xx >= cx1) continue;
+        }
         float pv = mu[i];
         pv = pv < dmin ? dmin : pv; pv = pv > dmax ? dmax : pv;        // test_MaGNet.py:72-75 (inf -> max, nan -> min)
         if (isinf(pv)) pv = dmax;
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256) void depth_metrics_kernel(const float* __restr
         acc[9] += (t < 1.25) ? 1.0 : 0.0; acc[10] += (t < 1.25 * 1.25) ? 1.0 : 0.0; acc[11] += (t < 1.25 * 1.25 * 1.25) ? 1.0 : 0.0;
         acc[12] += 0.5 * (log(var) + 1.8378770664093453 + d * d / var);    // ln(2 pi)
     }
-    __shared__ double red[4][13];
+    __shared__ double red[16][13];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
@@ -240,15 +248,17 @@ __global__ __launch_bounds__(256) void depth_metrics_kernel(const float* __restr
         if (lane == 0) red[wv][k] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 13) atomicAdd(sums + (size_t)b * MET_N + threadIdx.x,
-                                    red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < MET_N) {
+        double v = 0.0;
+        if (threadIdx.x < 13)
+            for (int w2 = 0; w2 < 16; ++w2) v += red[w2][threadIdx.x];
+        sums[(size_t)b * MET_N + threadIdx.x] = v;
+    }
 }
 
-hipError_t launch_depth_metrics(const float* pred, const float* gt, double* sums, int B, int HW, float dmin, float dmax, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(sums, 0, (size_t)B * MET_N * sizeof(double), s);
-    if (e != hipSuccess) return e;
-    const int nb = (HW + 256 * 8 - 1) / (256 * 8);
-    hipLaunchKernelGGL(depth_metrics_kernel, dim3((unsigned)(nb < 1 ? 1 : nb), (unsigned)B), dim3(256), 0, s, pred, gt, sums, HW, dmin, dmax);
+hipError_t launch_depth_metrics(const float* pred, const float* gt, double* sums, int B, int HW, int W, float dmin, float dmax,
+                                int cy0, int cy1, int cx0, int cx1, hipStream_t s) {
+    hipLaunchKernelGGL(depth_metrics_kernel, dim3((unsigned)B), dim3(1024), 0, s, pred, gt, sums, HW, W, dmin, dmax, cy0, cy1, cx0, cx1);
     return hipGetLastError();
 }
 

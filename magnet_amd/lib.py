@@ -465,7 +465,7 @@ def conv1x1_chain(in_hi, in_lo, w_hi, w_lo, bias, out, rows, cout_pad):
                                         _stream(in_hi)), "magnet_conv1x1_chain")
 
 
-API_SYMBOLS = API_SYMBOLS + ("magnet_depth_metrics", "magnet_make_rays", "magnet_relative_poses")
+API_SYMBOLS = API_SYMBOLS + ("magnet_depth_metrics", "magnet_depth_metrics_crop", "magnet_make_rays", "magnet_relative_poses")
 
 
 def make_rays(ray_params, h: int, w: int):

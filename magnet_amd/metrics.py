@@ -13,12 +13,27 @@ from . import lib
 METRIC_ORDER = ("abs_rel", "abs_diff", "sq_rel", "rmse", "rmse_log", "irmse", "log_10", "silog", "a1", "a2", "a3", "nll")
 
 
-def depth_metric_sums(pred: torch.Tensor, gt: torch.Tensor, min_depth: float, max_depth: float) -> torch.Tensor:
-    """pred (B,2,H,W) fp32 [mu, sigma]; gt (B,1,H,W) or (B,H,W) fp32 -> (B,16) float64 sums (device)."""
+def crop_window(kind, H: int, W: int):
+    """Evaluation window (y0, y1, x0, x1) of the reference's KITTI crops (test_MaGNet.py:63-71): 'garg' (Garg ECCV16),
+    'eigen' (Eigen NIPS14) or None (whole frame)."""
+    if kind in (None, "", "none"):
+        return None
+    if kind == "garg":
+        return int(0.40810811 * H), int(0.99189189 * H), int(0.03594771 * W), int(0.96405229 * W)
+    if kind == "eigen":
+        return int(0.3324324 * H), int(0.91351351 * H), int(0.0359477 * W), int(0.96405229 * W)
+    raise ValueError(f"unknown crop {kind!r}")
+
+
+def depth_metric_sums(pred: torch.Tensor, gt: torch.Tensor, min_depth: float, max_depth: float, crop=None) -> torch.Tensor:
+    """pred (B,2,H,W) fp32 [mu, sigma]; gt (B,1,H,W) or (B,H,W) fp32 -> (B,16) float64 sums (device).
+    crop: None, 'garg', 'eigen' or an explicit (y0, y1, x0, x1) window.  Fixed summation order: deterministic."""
     l = lib.load()
     if not getattr(l, "_metrics_proto", False):
         l.magnet_depth_metrics.restype = ctypes.c_int
         l.magnet_depth_metrics.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 2 + [ctypes.c_float] * 2 + [ctypes.c_void_p]
+        l.magnet_depth_metrics_crop.restype = ctypes.c_int
+        l.magnet_depth_metrics_crop.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 3 + [ctypes.c_float] * 2 + [ctypes.c_int32] * 4 + [ctypes.c_void_p]
         l._metrics_proto = True
     p = lib._dev(pred.detach().float().contiguous(), "pred", torch.float32)
     g = lib._dev(gt.detach().float().contiguous(), "gt", torch.float32)
@@ -26,9 +41,14 @@ def depth_metric_sums(pred: torch.Tensor, gt: torch.Tensor, min_depth: float, ma
     if two != 2 or g.numel() != B * H * W:
         raise lib.MagnetError(f"depth_metric_sums: pred {tuple(p.shape)} / gt {tuple(g.shape)} mismatch")
     sums = torch.empty((B, 16), dtype=torch.float64, device=p.device)
+    win = crop_window(crop, H, W) if isinstance(crop, (str, type(None))) else tuple(int(c) for c in crop)
     with torch.cuda.device(p.device):
-        lib._check(l.magnet_depth_metrics(p.data_ptr(), g.data_ptr(), sums.data_ptr(), B, H * W, float(min_depth),
-                                          float(max_depth), lib._stream(p)), "magnet_depth_metrics")
+        if win is None:
+            lib._check(l.magnet_depth_metrics(p.data_ptr(), g.data_ptr(), sums.data_ptr(), B, H * W, float(min_depth),
+                                              float(max_depth), lib._stream(p)), "magnet_depth_metrics")
+        else:
+            lib._check(l.magnet_depth_metrics_crop(p.data_ptr(), g.data_ptr(), sums.data_ptr(), B, H, W, float(min_depth),
+                                                   float(max_depth), *win, lib._stream(p)), "magnet_depth_metrics_crop")
     return sums
 
 
@@ -44,9 +64,9 @@ def metrics_from_sums(s) -> dict:
                 silog=math.sqrt(max(s[5] / n - mean_err * mean_err, 0.0)) * 100, nll=s[12] / n)
 
 
-def compute_depth_errors(pred, gt, min_depth, max_depth) -> list:
-    """Per-frame metric dicts for a batch (device reductions, one small D2H of B x 16 doubles)."""
-    return [metrics_from_sums(row) for row in depth_metric_sums(pred, gt, min_depth, max_depth).cpu().tolist()]
+def compute_depth_errors(pred, gt, min_depth, max_depth, crop=None) -> list:
+    """Per-frame metric dicts for a batch (device reductions, one small D2H of B x 16 doubles); crop: see depth_metric_sums."""
+    return [metrics_from_sums(row) for row in depth_metric_sums(pred, gt, min_depth, max_depth, crop).cpu().tolist()]
 
 
 class RunningAverage:

@@ -126,6 +126,32 @@ def test_depth_metrics_match_reference(hip_lib, gpu, golden):
             assert abs(got[b][k] - float(ref[k])) <= 2e-5 * max(1.0, abs(float(ref[k]))), (b, k, got[b][k], ref[k])
 
 
+def test_depth_metrics_kitti_crops_and_determinism(hip_lib, gpu):
+    """garg / eigen evaluation windows (test_MaGNet.py:63-71) against the same masking done in numpy + the oracle metrics, at the
+    KITTI evaluation size; and the sums are bit-identical run to run (fixed summation order, no atomics)."""
+    from magnet_amd import metrics as M
+    from oracle import oracle
+    H, W = 352, 1216
+    g = torch.Generator().manual_seed(6)
+    gt = torch.rand(1, 1, H, W, generator=g) * 90
+    gt[torch.rand(1, 1, H, W, generator=g) < 0.7] = 0.0                     # sparse LiDAR ground truth
+    pr = torch.rand(1, 2, H, W, generator=g) * 80 + 0.5
+    for kind in ("garg", "eigen"):
+        y0, y1, x0, x1 = M.crop_window(kind, H, W)
+        got = M.compute_depth_errors(pr.to(gpu), gt.to(gpu), 1e-3, 80.0, crop=kind)[0]
+        gtn = gt[0, 0].numpy().copy(); gtn[gtn > 80.0] = 0.0
+        mask = np.logical_and(gtn > 1e-3, gtn < 80.0)
+        ev = np.zeros_like(mask); ev[y0:y1, x0:x1] = True
+        mask &= ev
+        pn = np.clip(pr[0, 0].numpy(), 1e-3, 80.0)
+        ref = oracle.compute_depth_errors(gtn[mask], pn[mask], np.square(pr[0, 1].numpy())[mask])
+        for k in M.METRIC_ORDER:
+            assert abs(got[k] - float(ref[k])) <= 2e-5 * max(1.0, abs(float(ref[k]))), (kind, k, got[k], ref[k])
+    a = M.depth_metric_sums(pr.to(gpu), gt.to(gpu), 1e-3, 80.0)
+    for _ in range(3):
+        assert torch.equal(a, M.depth_metric_sums(pr.to(gpu), gt.to(gpu), 1e-3, 80.0))
+
+
 def test_eval_driver_runs(hip_lib, gpu, tmp_path):
     """The test_MaGNet.py-shaped loop end to end on tiny synthetic windows (one NaN pose -> a dropped view)."""
     import eval_synthetic as E
