@@ -154,6 +154,15 @@ MAGNET_API int magnet_make_rays(const double *ray_params, float *rays_out, int32
 MAGNET_API int magnet_relative_poses(const double *ext_ref, const double *ext_nghbr, float *poses_out, int32_t *is_valid_out,
                                      int32_t B, int32_t V, void *stream);
 
+/* The same backward with a caller-provided device workspace of magnet_cost_volume_f_backward_workspace(args) bytes: grad_src is then
+ * computed as a GATHER per source tile (cost_volume_f_gather.hip) — no atomics, deterministic, every interior texel of
+ * grad_src_pad stored exactly once (the one-texel border is left as the caller initialised it) — and grad_ref by the per-item
+ * kernel.  Shapes the gather path does not take fall back to the scatter kernels above (which accumulate: zero grad_src_pad
+ * first to be safe).  The workspace query returns -1 for invalid arguments. */
+MAGNET_API int64_t magnet_cost_volume_f_backward_workspace(const MagnetCostVolumeArgs *args);
+MAGNET_API int magnet_cost_volume_f_backward_ws(const MagnetCostVolumeArgs *args, const float *grad_cost, float *grad_ref_cl,
+                                     float *grad_src_pad, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* gmm_out[:,0] = mu + o0*sigma ; gmm_out[:,1] = (elu(o1) + 1 + 1e-10)*sigma.   All (B,2,h*w) fp32.
  * gmm_out may alias gmm_in. */
 MAGNET_API int magnet_gaussian_update(const float *gnet_out, const float *gmm_in, float *gmm_out,

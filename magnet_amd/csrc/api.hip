@@ -203,6 +203,38 @@ MAGNET_API int magnet_relative_poses(const double* ext_ref, const double* ext_ng
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_relative_poses launch");
 }
 
+MAGNET_API int64_t magnet_cost_volume_f_backward_workspace(const MagnetCostVolumeArgs* a) {
+    magnet::CvParams p;
+    if (cv_prepare(a, p, true)) return -1;
+    return (int64_t)magnet::cvf_gather_workspace_bytes(p);
+}
+
+MAGNET_API int magnet_cost_volume_f_backward_ws(const MagnetCostVolumeArgs* a, const float* grad_cost, float* grad_ref_cl,
+                                                float* grad_src_pad, void* workspace, int64_t workspace_bytes, void* stream) {
+    magnet::CvParams p;
+    if (const int rc = cv_prepare(a, p, true)) return rc;
+    if (a->mode != 1) return fail(MAGNET_E_DIM, "magnet_cost_volume_f_backward_ws: only mode 1 (est_costvolume_F) is differentiable");
+    if (a->feat_dtype != MAGNET_FEAT_F32) return fail(MAGNET_E_DTYPE, "magnet_cost_volume_f_backward_ws: fp32 features required");
+    if (!grad_cost || !grad_ref_cl || !grad_src_pad) return fail(MAGNET_E_NULL, "magnet_cost_volume_f_backward_ws: NULL gradient pointer");
+    if (!aligned16(grad_ref_cl) || !aligned16(grad_src_pad))
+        return fail(MAGNET_E_ALIGN, "magnet_cost_volume_f_backward_ws: gradient buffers must be 16-byte aligned");
+    bool ref_ok = false, src_ok = false;
+    hipError_t e = magnet::launch_cvf_bwd_ref_only(p, grad_cost, grad_ref_cl, (hipStream_t)stream, &ref_ok);
+    if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_f_backward_ws grad_ref launch");
+    if (ref_ok && !(p.ablate & 0x30)) {
+        e = magnet::launch_cvf_gather_src(p, grad_cost, grad_src_pad, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes,
+                                          (hipStream_t)stream, &src_ok);
+        if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_f_backward_ws grad_src launch");
+    }
+    if (ref_ok && src_ok) return 0;
+    // shapes / workspace the gather path does not take: the scatter kernels (grad_src_pad must have been zeroed by the caller)
+    bool handled = false;
+    e = magnet::launch_cvf_bwd(p, grad_cost, grad_ref_cl, grad_src_pad, (hipStream_t)stream, &handled);
+    if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_f_backward_ws launch");
+    if (!handled) return fail(MAGNET_E_DIM, "magnet_cost_volume_f_backward_ws: shape not supported (F > 128, V > 31 or image too large)");
+    return 0;
+}
+
 MAGNET_API int magnet_gaussian_update(const float* gnet_out, const float* gmm_in, float* gmm_out, int32_t B, int32_t hw,
                            void* stream) {
     if (!gnet_out || !gmm_in || !gmm_out) return fail(MAGNET_E_NULL, "magnet_gaussian_update: NULL pointer");

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 4) void cvf_bwd_kernel(const CvParams p, const
                             ga[cc].y = __builtin_fmaf(G, s.y, ga[cc].y);
                             ga[cc].z = __builtin_fmaf(G, s.z, ga[cc].z);
                             ga[cc].w = __builtin_fmaf(G, s.w, ga[cc].w);
-                            if (G != 0.f) {
+                            if (G != 0.f && grad_src) {                       // grad_src == nullptr: grad_ref only (cost_volume_f_gather.hip owns grad_src)
                                 float* gp = reinterpret_cast<float*>(gsrc + off + cc * 128);
                                 unsafeAtomicAdd(gp + 0, G * rv[cc].x);
                                 unsafeAtomicAdd(gp + 1, G * rv[cc].y);
@@ -380,6 +380,24 @@ __global__ __launch_bounds__(256, 2) void cvf_bwd_tile_kernel(const CvParams p, 
             flush(gsrc, ch_off);                                                  // end of this (tile, view, slice)
         }
     }
+}
+
+// grad_ref only (fully written, no atomics): the per-item kernel with its grad_src scatter switched off
+hipError_t launch_cvf_bwd_ref_only(const CvParams& p, const float* gout, float* grad_ref, hipStream_t stream, bool* handled) {
+    *handled = false;
+    if (p.feat_bf16) return hipSuccess;
+    if ((size_t)(p.h + 2) * (p.w + 2) >= ((size_t)1 << 24)) return hipSuccess;
+    if ((size_t)(p.h + 2) * (p.w + 2) * p.F * 4 >= ((size_t)1 << 32)) return hipSuccess;
+    const size_t lds = (size_t)4 * (p.V * 512 + 1088 + 272);
+    if (lds > 64 * 1024) return hipSuccess;
+    const int nchunk = p.F * 4 / 16;
+    const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
+    *handled = true;
+    if (nchunk <= 8)       hipLaunchKernelGGL((cvf_bwd_kernel<1>), grid, block, lds, stream, p, gout, grad_ref, (float*)nullptr);
+    else if (nchunk <= 16) hipLaunchKernelGGL((cvf_bwd_kernel<2>), grid, block, lds, stream, p, gout, grad_ref, (float*)nullptr);
+    else if (nchunk <= 32) hipLaunchKernelGGL((cvf_bwd_kernel<4>), grid, block, lds, stream, p, gout, grad_ref, (float*)nullptr);
+    else { *handled = false; return hipSuccess; }
+    return hipGetLastError();
 }
 
 hipError_t launch_cvf_bwd(const CvParams& p, const float* gout, float* grad_ref, float* grad_src, hipStream_t stream,

@@ -90,5 +90,9 @@ hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cv_fast64(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cvf_bwd(const CvParams& p, const float* gout, float* grad_ref, float* grad_src, hipStream_t stream,
                           bool* handled);
+hipError_t launch_cvf_bwd_ref_only(const CvParams& p, const float* gout, float* grad_ref, hipStream_t stream, bool* handled);
+size_t cvf_gather_workspace_bytes(const CvParams& p);
+hipError_t launch_cvf_gather_src(const CvParams& p, const float* gout, float* grad_src, void* workspace, size_t ws_bytes, hipStream_t stream,
+                                 bool* handled);
 
 }  // namespace magnet

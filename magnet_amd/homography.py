@@ -150,10 +150,11 @@ class _CostVolumeF(torch.autograd.Function):
     (cost_volume_f_bwd.hip).  Features are differentiable; bins, poses and intrinsics are data."""
 
     @staticmethod
-    def forward(ctx, ref_feat, nghbr_feat, bins, poses, is_valid, intM, rays, path):
+    def forward(ctx, ref_feat, nghbr_feat, bins, poses, is_valid, intM, rays, path, bwd_path=0):
         ref_cl = lib.pack_features(ref_feat.detach().float().contiguous(), lib.FEAT_F32, pad=0)
         src_pad = lib.pack_features(nghbr_feat.detach().float().contiguous(), lib.FEAT_F32, pad=1)
         ctx.bins = bins
+        ctx.bwd_path = bwd_path
         ctx.save_for_backward(ref_cl, src_pad, poses, is_valid, intM, rays)
         return lib.cost_volume_cw(ref_cl, src_pad, None, poses, is_valid, intM, rays, 0.0, k_list=bins,
                                   path=path, mode=1)
@@ -162,14 +163,14 @@ class _CostVolumeF(torch.autograd.Function):
     def backward(ctx, grad_cost):
         ref_cl, src_pad, poses, is_valid, intM, rays = ctx.saved_tensors
         g_ref_cl, g_src_pad = lib.cost_volume_f_backward(ref_cl, src_pad, poses, is_valid, intM, rays, ctx.bins,
-                                                         grad_cost.float().contiguous())
+                                                         grad_cost.float().contiguous(), path=ctx.bwd_path)
         # channel-last -> NCHW (+ drop the gradient of the zero padding): layout plumbing, outside the hot loop
         g_ref = g_ref_cl.permute(0, 3, 1, 2).contiguous()
         g_src = g_src_pad[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).contiguous()
-        return g_ref, g_src, None, None, None, None, None, None
+        return g_ref, g_src, None, None, None, None, None, None, None
 
 
-def est_costvolume_F(d_center, ref_feat, nghbr_feat, R, t, is_valid, cam_intrins, path: int = 0):
+def est_costvolume_F(d_center, ref_feat, nghbr_feat, R, t, is_valid, cam_intrins, path: int = 0, bwd_path: int = 0):
     """Drop-in for homography.est_costvolume_F (reference homography.py:10-46), the matching volume the
     F-Net is trained through (MAGNET.py:197-200): differentiable w.r.t. ref_feat and nghbr_feat.
 
@@ -184,5 +185,5 @@ def est_costvolume_F(d_center, ref_feat, nghbr_feat, R, t, is_valid, cam_intrins
     iv = _valid_to_device(is_valid, dev)
     intM = _to_device_cached(cam_intrins["intM"], dev, torch.float32, _INTRINS_CACHE)
     rays = _to_device_cached(cam_intrins["unit_ray_array_2D"], dev, torch.float32, _INTRINS_CACHE)
-    raw = _CostVolumeF.apply(ref_feat, nghbr_feat, bins, poses, iv, intM, rays, path)
+    raw = _CostVolumeF.apply(ref_feat, nghbr_feat, bins, poses, iv, intM, rays, path, bwd_path)
     return torch.softmax(raw, dim=1)                                   # homography.py:45

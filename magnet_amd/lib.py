@@ -20,7 +20,8 @@ MAX_CANDIDATES = 256
 
 API_SYMBOLS = ("magnet_version", "magnet_last_error", "magnet_device_count", "magnet_pack_features",
                "magnet_pack_gmm",
-               "magnet_cost_volume_cw", "magnet_cost_volume_f_backward", "magnet_gaussian_update",
+               "magnet_cost_volume_cw", "magnet_cost_volume_f_backward", "magnet_cost_volume_f_backward_ws",
+               "magnet_cost_volume_f_backward_workspace", "magnet_gaussian_update",
                "magnet_upsample_depth")
 
 
@@ -285,9 +286,23 @@ def cost_volume_f_backward(ref_feat_cl, src_feat_pad, poses, is_valid, intM, ray
     a.poses, a.is_valid, a.intM, a.rays = po.data_ptr(), iv.data_ptr(), K.data_ptr(), ry.data_ptr()
     grad_ref = torch.empty_like(r)
     grad_src = torch.zeros_like(s)
+    l = load()
     with torch.cuda.device(r.device):
-        _check(load().magnet_cost_volume_f_backward(ctypes.byref(a), g.data_ptr(), grad_ref.data_ptr(),
-                                                    grad_src.data_ptr(), _stream(r)), "magnet_cost_volume_f_backward")
+        if (int(path) & 0xff) == 0:
+            # gather path: deterministic, no atomics; workspace = projection terms + per-(view, bin, tile) bounding boxes
+            l.magnet_cost_volume_f_backward_workspace.restype = ctypes.c_int64
+            l.magnet_cost_volume_f_backward_workspace.argtypes = [ctypes.c_void_p]
+            l.magnet_cost_volume_f_backward_ws.restype = ctypes.c_int
+            l.magnet_cost_volume_f_backward_ws.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
+            nbytes = int(l.magnet_cost_volume_f_backward_workspace(ctypes.byref(a)))
+            if nbytes < 0:
+                raise MagnetError("magnet_cost_volume_f_backward_workspace: " + l.magnet_last_error().decode())
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=r.device)
+            _check(l.magnet_cost_volume_f_backward_ws(ctypes.byref(a), g.data_ptr(), grad_ref.data_ptr(), grad_src.data_ptr(),
+                                                      ws.data_ptr(), nbytes, _stream(r)), "magnet_cost_volume_f_backward_ws")
+        else:
+            _check(l.magnet_cost_volume_f_backward(ctypes.byref(a), g.data_ptr(), grad_ref.data_ptr(),
+                                                   grad_src.data_ptr(), _stream(r)), "magnet_cost_volume_f_backward")
     return grad_ref, grad_src
 
 

@@ -117,8 +117,9 @@ def test_backward_rejects_bad_mode(hip_lib, gpu):
 
 
 def test_backward_kernels_agree(hip_lib, gpu):
-    """Tile-privatised backward (LDS hash table, default) vs the per-item atomic kernel (path bit 0x2000) vs the oracle,
-    on a shape with long epipolar runs (table pressure) and an invalid view."""
+    """Gather backward (default: no atomics, deterministic) vs the tile-privatised scatter kernel (LDS hash table, path bit
+    0x1000) vs the per-item atomic kernel (path bit 0x2000) vs the oracle, on a shape with long epipolar runs and an invalid
+    view; the gather path must also be bit-identical run to run."""
     from magnet_amd import lib
     wl = synth.Workload("f", "scannet", 28, 36, V=3, D=80, F=64)
     inp = synth.make_inputs(wl, B=2, seed=21, invalid=[(1, 0)])
@@ -132,7 +133,9 @@ def test_backward_kernels_agree(hip_lib, gpu):
     bins = [float(v) for v in dc.reshape(-1)]
     common = (ref_cl, src_pad, inp["nghbr_poses"].to(gpu), inp["is_valid"].int().to(gpu), inp["cam_intrins"]["intM"].to(gpu),
               inp["cam_intrins"]["unit_ray_array_2D"].to(gpu), bins, gout.to(gpu))
-    for path in (0, 0x2000):
+    a1 = lib.cost_volume_f_backward(*common, path=0x4000); a2 = lib.cost_volume_f_backward(*common, path=0x4000)
+    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1])      # private-copy gather variant: fixed summation order
+    for path in (0, 0x4000, 0x1000, 0x2000):
         gr, gs = lib.cost_volume_f_backward(*common, path=path)
         gr = gr.permute(0, 3, 1, 2).cpu().numpy(); gs = gs[:, 1:-1, 1:-1].permute(0, 3, 1, 2).cpu().numpy()
         for got, exp in ((gr, o_gr), (gs, o_gs)):

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--path", type=lambda x: int(x, 0), default=0, help="backward kernel: 0 gather (default), 0x4000 gather with private "
+                    "accumulator copies, 0x1000 LDS hash-table scatter, 0x2000 per-item atomics")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     for name, s in SHAPES.items():
@@ -34,7 +36,7 @@ def main():
         dcd = dc.to(dev)
 
         def step():
-            cv = homography.est_costvolume_F(dc, rf, sf, R, t, inp["is_valid"], inp["cam_intrins"])
+            cv = homography.est_costvolume_F(dc, rf, sf, R, t, inp["is_valid"], inp["cam_intrins"], bwd_path=a.path)
             loss = (cv * dcd).sum(dim=1).abs().mean()                 # train_FNet.py:96 expectation + an L1-like loss
             rf.grad = None; sf.grad = None
             loss.backward()
@@ -46,7 +48,7 @@ def main():
             step()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
         rec = {"shape": name, "B": a.batch, "V": s["V"], "D": D, "F": 64, "h": s["h"], "w": s["w"],
-               "ms_fwd_bwd": dt * 1e3, "frames_per_s": a.batch / dt}
+               "ms_fwd_bwd": dt * 1e3, "frames_per_s": a.batch / dt, "bwd_path": hex(a.path)}
         if a.cpu:
             from oracle import oracle
             nb = min(2, a.batch)
