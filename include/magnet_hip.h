@@ -155,7 +155,7 @@ MAGNET_API int magnet_relative_poses(const double *ext_ref, const double *ext_ng
                                      int32_t B, int32_t V, void *stream);
 
 /* The same backward with a caller-provided device workspace of magnet_cost_volume_f_backward_workspace(args) bytes: grad_src is then
- * computed as a GATHER per source tile (cost_volume_f_gather.hip) — no atomics, deterministic, every interior texel of
+ * computed as a GATHER per source row segment (cost_volume_f_gather.hip) — no atomics, deterministic, every interior texel of
  * grad_src_pad stored exactly once (the one-texel border is left as the caller initialised it) — and grad_ref by the per-item
  * kernel.  Shapes the gather path does not take fall back to the scatter kernels above (which accumulate: zero grad_src_pad
  * first to be safe).  The workspace query returns -1 for invalid arguments. */

@@ -83,13 +83,15 @@ __global__ __launch_bounds__(64) void cvf_prep_kernel(const CvParams p, float4* 
     }
 }
 
-constexpr int GS_LIST = 256;                             // (pixel, tap) pairs of one reference tile landing in a segment: <= 64 * 4
+constexpr int GS_LIST = 64;                              // pixels of one reference tile whose quad touches a segment: <= 64
 
 // One WAVE per (frame, view, source row segment of SW texels): fully independent waves (no workgroup barrier, no shared state), lane =
-// pixel while re-projecting, lane = channel while accumulating.  LDS per wave: SW x 256 B of accumulators + the 2 KB pair list, so
-// 16 (SW = 32) to 26 (SW = 16) waves fit a CU — the first version gave every wave a 64-texel copy (16 KB: 8 waves per CU) and was
-// bound by the latency of its dependent chain (list entry -> reference row load -> LDS read-modify-write); a shared tile updated
-// with ds_add_f32 instead is 4x slower still (LDS float atomics retire about one lane per clock).
+// pixel while re-projecting, lane = channel while accumulating.  LDS per wave: (SW + 2) x 256 B of accumulators + the 1 KB pixel list,
+// so 28 waves (SW = 16) fit a CU.  Measured history on 16 ScanNet-shape frames (fwd + bwd): LDS hash scatter with atomics 53.5 ms;
+// workgroup per 16x4 source tile with one 64-texel accumulator copy per wave (16 KB each: 8 waves per CU, bound by the latency of
+// the chain list entry -> reference row load -> LDS read-modify-write) 27.7 ms; the same tile shared and updated with ds_add_f32
+// 105 ms (LDS float atomics retire about one lane per clock); wave per row segment 21.6 ms; one list entry per PIXEL (its two
+// taps on this row share the reference row load) 17.2 ms.
 // grid = (ceil(B * V * h * segments / 4), channel blocks of 64); 256 threads = 4 independent waves
 template <int SW>
 __global__ __launch_bounds__(256) void cvf_gather_src_kernel(const CvParams p, const float* __restrict__ gout, float* __restrict__ grad_src,
@@ -97,9 +99,9 @@ __global__ __launch_bounds__(256) void cvf_gather_src_kernel(const CvParams p, c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int WAVE_LDS = SW * 256 + GS_LIST * 8;
-    float* acc = reinterpret_cast<float*>(smem + wv * WAVE_LDS);                              // [SW texels][64 channels]
-    uint2* list = reinterpret_cast<uint2*>(smem + wv * WAVE_LDS + SW * 256);                  // {slot | pixel << 8, coef}
+    constexpr int WAVE_LDS = (SW + 2) * 256 + GS_LIST * 16;
+    float* acc = reinterpret_cast<float*>(smem + wv * WAVE_LDS);                              // [guard, SW texels, guard][64 channels]
+    uint4* list = reinterpret_cast<uint4*>(smem + wv * WAVE_LDS + (SW + 2) * 256);            // {left slot | pixel << 8, coefficients}
     const long long unit = (long long)blockIdx.x * 4 + wv;                                    // (frame, view, row, segment)
     const long long nunits = (long long)p.B * p.V * p.h * segs_x;
     if (unit >= nunits) return;                           // wave-uniform; nothing below synchronises across waves
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void cvf_gather_src_kernel(const CvParams p, c
     const int Wp = p.w + 2, Hp = p.h + 2;
     const size_t hw = (size_t)p.h * p.w;
     const int ntiles = p.tiles_x * p.tiles_y;
-    for (int e = lane; e < SW * 64; e += 64) acc[e] = 0.f;
+    for (int e = lane; e < (SW + 2) * 64; e += 64) acc[e] = 0.f;
     gat_lds_fence();
     const bool valid = p.is_valid[b * p.V + v] == 1;      // homography.py:26 (wave-uniform)
     if (valid) {
@@ -148,36 +150,38 @@ __global__ __launch_bounds__(256) void cvf_gather_src_kernel(const CvParams p, c
                     int x0, y0; bool inwin;
                     const Taps tw = make_taps(ix, iy, fw, fh, x0, y0, inwin);
                     const float G = (pin && inwin) ? gj[pix] / fV : 0.f;                      // d(cost)/d(view sum), homography.py:46
+                    // a pixel's quad touches this row with its top taps (nw, ne) or its bottom taps (sw, se), never both: one list
+                    // entry per pixel = {left slot | pixel << 8, left coefficient, right coefficient}; slots are shifted by one
+                    // guard texel on either side so that a quad straddling the segment's end needs no test
                     const int lx0 = x0 + 1 - SX, ly0 = y0 + 1 - SY;
-                    int n = 0;
-#pragma unroll
-                    for (int tap = 0; tap < 4; ++tap) {
-                        const int lx = lx0 + (tap & 1), ly = ly0 + (tap >> 1);
-                        const float wt = tap == 0 ? tw.nw : (tap == 1 ? tw.ne : (tap == 2 ? tw.sw : tw.se));
-                        const bool ok = (G != 0.f) && ((unsigned)lx < (unsigned)SW) && (ly == 0);
-                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(ok);
-                        const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                        if (ok) list[pos] = make_uint2((uint32_t)lx | (pix << 8), __float_as_uint(G * wt));
-                        n += __popcll(bal);
+                    const bool top = ly0 == 0;
+                    const bool ok = (G != 0.f) && (top || ly0 == -1) && ((unsigned)(lx0 + 1) <= (unsigned)SW);
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(ok);
+                    const int n = __popcll(bal);
+                    if (ok) {
+                        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                        list[pos] = make_uint4((uint32_t)(lx0 + 1) | (pix << 8), __float_as_uint(G * (top ? tw.nw : tw.sw)),
+                                               __float_as_uint(G * (top ? tw.ne : tw.se)), 0u);
                     }
                     gat_lds_fence();
                     // ---- apply: lane = channel, plain read-modify-write (in-order LDS, wave-private accumulators) ----
                     constexpr int NB = 8;
                     for (int k0 = 0; k0 < n; k0 += NB) {
-                        uint2 e[NB]; float rv[NB];
+                        uint4 e[NB]; float rv[NB];
 #pragma unroll
                         for (int i = 0; i < NB; ++i) e[i] = list[min(k0 + i, n - 1)];         // wave-uniform address: broadcast read
 #pragma unroll
                         for (int i = 0; i < NB; ++i) {
                             const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[i].x);
-                            rv[i] = chan ? refc[(size_t)(pk >> 8) * p.F] : 0.f;               // 256 contiguous bytes per pair
+                            rv[i] = chan ? refc[(size_t)(pk >> 8) * p.F] : 0.f;               // 256 contiguous bytes per pixel
                             e[i].x = pk;
                         }
 #pragma unroll
                         for (int i = 0; i < NB; ++i) {
                             if (k0 + i < n) {                                                 // wave-uniform
                                 float* cell = acc + (e[i].x & 255u) * 64 + lane;
-                                *cell = __builtin_fmaf(__uint_as_float(e[i].y), rv[i], *cell);
+                                cell[0] = __builtin_fmaf(__uint_as_float(e[i].y), rv[i], cell[0]);
+                                cell[64] = __builtin_fmaf(__uint_as_float(e[i].z), rv[i], cell[64]);
                             }
                         }
                     }
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void cvf_gather_src_kernel(const CvParams p, c
     float* __restrict__ gdst = grad_src + (size_t)((size_t)v * p.B + b) * Hp * Wp * p.F + ((size_t)SY * Wp) * p.F;
     if (chan)
         for (int tx = 0; tx < SW; ++tx)
-            if (SX + tx <= p.w) gdst[(size_t)(SX + tx) * p.F + cb + lane] = acc[tx * 64 + lane];
+            if (SX + tx <= p.w) gdst[(size_t)(SX + tx) * p.F + cb + lane] = acc[(tx + 1) * 64 + lane];
 }
 
 size_t cvf_gather_workspace_bytes(const CvParams& p) {
@@ -211,15 +215,14 @@ hipError_t launch_cvf_gather_src(const CvParams& p, const float* gout, float* gr
     hipLaunchKernelGGL(cvf_prep_kernel, dim3((unsigned)((size_t)p.B * p.V * ntiles)), dim3(64), 0, stream, p, pvt, boxes);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // 16-texel segments: 6 KB of LDS per wave, 26 waves per CU.  dev (path bit 14): 32-texel segments (16 waves per CU, fewer
-    // duplicated tile re-projections); dev (path bit 15): 8-texel segments.
-    const int SWv = (p.ablate & 0x40) ? 32 : ((p.ablate & 0x80) ? 8 : 16);
+    // 16-texel segments: 5.5 KB of LDS per wave, 28 waves per CU.  dev (path bit 14): 32-texel segments (fewer duplicated tile
+    // re-projections, 16 waves per CU): 12 % slower on both training shapes; 8-texel segments were 3 - 13 % slower.
+    const int SWv = (p.ablate & 0x40) ? 32 : 16;
     const int segs_x = (p.w + SWv - 1) / SWv;
     const long long nunits = (long long)p.B * p.V * p.h * segs_x;
     const dim3 grid((unsigned)((nunits + 3) / 4), (unsigned)((p.F + 63) / 64));
-    const size_t lds = (size_t)4 * (SWv * 256 + GS_LIST * 8);
+    const size_t lds = (size_t)4 * ((SWv + 2) * 256 + GS_LIST * 16);
     if (SWv == 32)      hipLaunchKernelGGL(cvf_gather_src_kernel<32>, grid, dim3(256), lds, stream, p, gout, grad_src, pvt, boxes, segs_x);
-    else if (SWv == 8)  hipLaunchKernelGGL(cvf_gather_src_kernel<8>, grid, dim3(256), lds, stream, p, gout, grad_src, pvt, boxes, segs_x);
     else                hipLaunchKernelGGL(cvf_gather_src_kernel<16>, grid, dim3(256), lds, stream, p, gout, grad_src, pvt, boxes, segs_x);
     return hipGetLastError();
 }

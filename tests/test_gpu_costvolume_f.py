@@ -133,9 +133,9 @@ def test_backward_kernels_agree(hip_lib, gpu):
     bins = [float(v) for v in dc.reshape(-1)]
     common = (ref_cl, src_pad, inp["nghbr_poses"].to(gpu), inp["is_valid"].int().to(gpu), inp["cam_intrins"]["intM"].to(gpu),
               inp["cam_intrins"]["unit_ray_array_2D"].to(gpu), bins, gout.to(gpu))
-    a1 = lib.cost_volume_f_backward(*common, path=0x4000); a2 = lib.cost_volume_f_backward(*common, path=0x4000)
-    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1])      # private-copy gather variant: fixed summation order
-    for path in (0, 0x4000, 0x1000, 0x2000):
+    a1 = lib.cost_volume_f_backward(*common, path=0); a2 = lib.cost_volume_f_backward(*common, path=0)
+    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1])      # production gather: fixed summation order, no atomics
+    for path in (0, 0x4000, 0x1000, 0x2000):                            # gather (16- / 32-texel segments), hash scatter, plain atomics
         gr, gs = lib.cost_volume_f_backward(*common, path=path)
         gr = gr.permute(0, 3, 1, 2).cpu().numpy(); gs = gs[:, 1:-1, 1:-1].permute(0, 3, 1, 2).cpu().numpy()
         for got, exp in ((gr, o_gr), (gs, o_gs)):
