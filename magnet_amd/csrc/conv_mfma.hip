@@ -60,20 +60,22 @@ __device__ __forceinline__ int act_swz(int row, int slot) { return row * 256 + (
 // from the LDS tile (act_swz layout), weight fragments straight from global memory (64 KB per layer, L2-resident; no LDS
 // staging, so no barrier: the rows are wave-private).  Operands are swapped (weights = MFMA A operand): the accumulator is
 // C^T — a lane holds 4 CONSECUTIVE output channels of one row.
-template <int NF, bool LAST>
+template <int NF, bool LAST, int MT = 2>
 __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, const uint16_t* __restrict__ w_lo,
                                            const float* __restrict__ bias, unsigned char* act_hi, unsigned char* act_lo,
                                            float* __restrict__ out, int out_ld, long long row0, long long rows, int lane, int wv) {
-    f32x4_t acc[NF][2];
+    f32x4_t acc[NF][MT];
 #pragma unroll
-    for (int n = 0; n < NF; ++n) { acc[n][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[n][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, kslot = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        bf16x8_t xh[2], xl[2];
+        bf16x8_t xh[MT], xl[MT];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int row = wv * 32 + m * 16 + frow;
+        for (int m = 0; m < MT; ++m) {
+            const int row = wv * (MT * 16) + m * 16 + frow;
             xh[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_hi + act_swz(row, kk * 4 + kslot)));
             xl[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_lo + act_swz(row, kk * 4 + kslot)));
         }
@@ -82,12 +84,12 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
             const size_t e = (size_t)(n * 16 + frow) * 128 + kk * 32 + kslot * 8;
             const bf16x8_t wh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_hi + e));
             const bf16x8_t wl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_lo + e));
-            acc[n][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[0], acc[n][0], 0, 0, 0);
-            acc[n][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[1], acc[n][1], 0, 0, 0);
-            acc[n][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[0], acc[n][0], 0, 0, 0);
-            acc[n][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[1], acc[n][1], 0, 0, 0);
-            acc[n][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[0], acc[n][0], 0, 0, 0);
-            acc[n][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[1], acc[n][1], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[m], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[m], acc[n][m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[m], acc[n][m], 0, 0, 0);
         }
     }
     // all of this wave's reads of its rows are done (same wave, in-order LDS); publish the layer's output in place
@@ -96,9 +98,9 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
 #pragma unroll
     for (int n = 0; n < NF; ++n)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MT; ++m) {
             const int ch = n * 16 + (lane >> 4) * 4;
-            const int trow = wv * 32 + m * 16 + (lane & 15);
+            const int trow = wv * (MT * 16) + m * 16 + (lane & 15);
             const float4 b4 = *reinterpret_cast<const float4*>(bias + ch);
             float v[4] = {acc[n][m][0] + b4.x, acc[n][m][1] + b4.y, acc[n][m][2] + b4.z, acc[n][m][3] + b4.w};
             if constexpr (!LAST) {
@@ -127,9 +129,14 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
 // WIN = row-window K loop: the taps of one tap ROW (ty fixed, tx = 0..tap_n-1) read the same activation rows shifted by tap_sx, so
 // their A operand is staged ONCE per (K chunk, ty) as a window of CV_BM + (tap_n-1)*tap_sx rows and the tx sub-steps read their
 // fragments at a row offset; only the weight tile changes per sub-step.  L2 requests per 3x3 tap row: 272 + 3*256 instead of
-// 3*(256 + 256) (counters: the kernel is L2-request-bound, TCC ~82 % busy, profiles/r2/pmc_conv_*.txt).
-template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, bool WIN = false>
-__global__ __launch_bounds__(NT) void conv_mfma_kernel(const ConvParams p) {
+// 3*(256 + 256).  WIN = 1: two window slots + two weight slots in LDS, one flat loop over the sub-steps (2x2 taps, dev A/B).
+// WIN = 2 (3x3 layers, default): the window's fragments for all three tx are held in registers, one window slot + a 3-slot weight
+// ring with counted vmcnt waits (prefetch distance 2).
+// __launch_bounds__(NT, 2): two waves per SIMD is what the LDS budget allows anyway, and with <= 256 registers hipcc selects the
+// VGPR form of the MFMAs — with the default bound it kept the accumulators in AGPRs and moved all 64 of them through VGPRs
+// (64 v_accvgpr_read + 64 v_accvgpr_write) on every trip of the K loop.
+template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, int WIN = 0>
+__global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins do not exist in the host pass (which only needs the stub)
     constexpr int BN = NF * 16;
     constexpr int RP = NT / 4;                        // tile rows filled by one DMA instruction per wave set (4 lanes per 64-byte row)
@@ -256,7 +263,107 @@ __global__ __launch_bounds__(NT) void conv_mfma_kernel(const ConvParams p) {
         }
     };
 
-    if constexpr (WIN) {
+    if constexpr (WIN == 2) {
+        // ---- row-window loop, prefetch distance 2 (3x3 layers): the window's fragments for all three tx live in REGISTERS
+        // (read once per group), so one LDS window slot suffices and the weight tiles get a 3-slot ring: stage s+2's LDS-DMA is
+        // issued right after the barrier of sub-step s and stays in flight across two barriers behind counted s_waitcnt vmcnt
+        // (loads retire in order: "all but the pieces issued in the previous sub-step" = stage s landed).  Issuing the pieces
+        // later in the sub-step, between the MFMAs, was measured 2.5 % slower (same box A/B).  3 sub-steps per
+        // group and 3 slots: stage s = 3g + tx lives in slot tx — every LDS address below is static.
+        static_assert(!PP && SPB == 1 && NT == 256 && BN % RP == 0, "window loop with register-resident A: 4 waves, whole DMA passes");
+        // Measured and rejected: the same loop with a 2-slot weight ring and a two-pass (2 x 64 rows) fused tail so that THREE
+        // workgroups fit a CU (49 KB of LDS, <= 168 registers): 96 of the 168 registers hold the window, the compiler serialises the
+        // weight fragment reads with the MFMAs: 9.4 vs 5.0 ms of convolutions per C2 step.
+        constexpr int BP = 2 * B_PT;                          // weight-tile DMA instructions per wave and stage
+        constexpr int AP = 2 * A_PT;                          // window DMA instructions per wave (wave 0: + 2 for the rows past the tile)
+        unsigned char* const a_win = smem;                    // [hi | lo], AW_ROWS rows each
+        unsigned char* const b_ring = smem + 2 * A_BYTES;     // 3 x [hi | lo]
+        const int aw = CV_BM + 2 * p.tap_sx;
+        const int ngroups = 3 * ksteps_per_tap;               // (K chunk, ty) pairs, ty inner
+        int g_ty = 0, g_k0 = 0, bs_tap = 0, bs_k0 = 0;
+        auto dma_a = [&]() {
+            unsigned char* sa_hi = a_win;
+            unsigned char* sa_lo = sa_hi + A_BYTES;
+            const int a_u = (((g_ty + p.tap_o0) * p.tap_sy + p.tap_o0 * p.tap_sx) * p.in_ld + g_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < A_PT; ++i) {
+                CV_BLDS(ra_hi, sa_hi + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+                CV_BLDS(ra_lo, sa_lo + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+            }
+            if (wv == 0 && st_r < aw - CV_BM) {
+                const int ax = a_v[0] + CV_BM * p.in_ld * 2;
+                CV_BLDS(ra_hi, sa_hi + CV_BM * CV_ROW, ax + a_u);
+                CV_BLDS(ra_lo, sa_lo + CV_BM * CV_ROW, ax + a_u);
+            }
+            if (++g_ty == 3) { g_ty = 0; g_k0 += CV_BK; }
+        };
+        auto dma_b = [&](int slot) {
+            unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
+            unsigned char* sb_lo = sb_hi + B_BYTES;
+            const int b_u = (bs_tap * p.cout_pad * p.cin + bs_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < B_PT; ++i) {
+                CV_BLDS(rb_hi, sb_hi + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+                CV_BLDS(rb_lo, sb_lo + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+            }
+            if (++bs_tap == 9) { bs_tap = 0; bs_k0 += CV_BK; }
+        };
+        int a_offx[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) a_offx[tx] = cv_swz(wm * (MF * 16) + frow + tx * p.tap_sx, lane >> 4);
+        bf16x8_t ah[3][MF], al[3][MF];
+        auto mfma_b = [&](int slot, const bf16x8_t (&xh)[MF], const bf16x8_t (&xl)[MF]) {
+            const unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
+            const unsigned char* sb_lo = sb_hi + B_BYTES;
+            bf16x8_t fbh[NFW], fbl[NFW];
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+                fbh[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
+                fbl[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_lo + b_off + n * 16 * CV_ROW));
+            }
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+                const bf16x8_t bh = fbh[n], bl = fbl[n];
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[m], bh, acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[m], bl, acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[m], bh, acc[m][n], 0, 0, 0);
+            }
+        };
+#define CV_WAIT_BARRIER(N)                                                                     \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");                    \
+        __builtin_amdgcn_s_barrier();                                                          \
+        asm volatile("" ::: "memory");
+        dma_a();
+        dma_b(0);
+        dma_b(1);
+        for (int g = 0; g < ngroups; ++g) {
+            const bool lastg = g + 1 == ngroups;
+            // ---- tx = 0: stage 3g (slot 0) and window g have landed; refill slot 2 with stage 3g + 2 ----
+            CV_WAIT_BARRIER(BP)
+            dma_b(2);
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int m = 0; m < MF; ++m) {
+                    ah[tx][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + a_offx[tx] + m * 16 * CV_ROW));
+                    al[tx][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + A_BYTES + a_offx[tx] + m * 16 * CV_ROW));
+                }
+            mfma_b(0, ah[0], al[0]);
+            // ---- tx = 1: every wave holds window g in registers (lgkmcnt(0) before the barrier): fetch window g + 1 ----
+            CV_WAIT_BARRIER(BP)
+            if (!lastg) { dma_b(0); dma_a(); }
+            mfma_b(1, ah[1], al[1]);
+            // ---- tx = 2 (the window's pieces, issued after the weight pieces, stay in flight) ----
+            if (!lastg) { CV_WAIT_BARRIER(BP + AP) dma_b(1); }
+            else { CV_WAIT_BARRIER(0) }
+            mfma_b(2, ah[2], al[2]);
+        }
+#undef CV_WAIT_BARRIER
+        __syncthreads();                                      // nothing in flight; the ring is dead (the epilogue reuses it)
+    } else if constexpr (WIN == 1) {
         static_assert(!PP && SPB == 1, "row-window loop: 2-slot ring");
         // LDS: [A window slot 0 | A window slot 1 | B slot 0 | B slot 1], each hi + lo
         unsigned char* const a_ring = smem;
@@ -324,17 +431,20 @@ __global__ __launch_bounds__(NT) void conv_mfma_kernel(const ConvParams p) {
         dma_a(0);
         dma_b(0);
         __syncthreads();
-        int bslot = 0;
-        for (int g = 0; g < ngroups; ++g) {
-            const int aslot = g & 1;
-            for (int tx = 0; tx < p.tap_n; ++tx) {
-                const bool last_tx = tx + 1 == p.tap_n;
-                if (!(last_tx && g + 1 == ngroups)) dma_b(bslot ^ 1);              // next sub-step's weights
-                if (last_tx && g + 1 < ngroups) dma_a(aslot ^ 1);                  // next group's window
-                compute_w(aslot, bslot, tx == 0 ? a_offx[0] : (tx == 1 ? a_offx[1] : a_offx[2]));
-                __syncthreads();
-                bslot ^= 1;
-            }
+        // ONE flat loop over the sub-steps (group g = (K chunk, ty), tx inner) with a single MFMA block per iteration: as a
+        // g / tx loop nest the compiler peeled tx into three copies plus a remainder loop and resolved the accumulator phis
+        // with 64 register moves (128 v_accvgpr moves before __launch_bounds__(NT, 2)) per group, draining the MFMA pipe.
+        int bslot = 0, aslot = 0, tx = 0, a_of = a_offx[0];
+        const int nsub = ngroups * p.tap_n;
+        for (int s = 0; s < nsub; ++s) {
+            const bool last_tx = tx + 1 == p.tap_n;
+            if (s + 1 < nsub) dma_b(bslot ^ 1);                                    // next sub-step's weights
+            if (last_tx && s + 1 < nsub) dma_a(aslot ^ 1);                         // next group's window
+            compute_w(aslot, bslot, a_of);
+            __syncthreads();
+            bslot ^= 1;
+            if (last_tx) { tx = 0; aslot ^= 1; a_of = a_offx[0]; }
+            else { ++tx; a_of = tx == 1 ? a_offx[1] : a_offx[2]; }
         }
     } else
     if constexpr (PP) {
@@ -545,14 +655,15 @@ __global__ __launch_bounds__(NT) void conv_mfma_kernel(const ConvParams p) {
 #endif
 }
 
-template <int NF, int WN, int BM, int SPB, int NT = 256, bool PP = false, bool WIN = false>
+template <int NF, int WN, int BM, int SPB, int NT = 256, bool PP = false, int WIN = 0>
 static size_t conv_lds_bytes() {
-    const size_t tiles = (PP ? 3 : 2 * SPB) * (2 * (size_t)(WIN ? BM + 8 : BM) * CV_ROW + 2 * (size_t)(NF * 16) * CV_ROW);
+    const size_t tiles = WIN == 2 ? 2 * (size_t)(BM + 8) * CV_ROW + 3 * 2 * (size_t)(NF * 16) * CV_ROW
+                                  : (PP ? 3 : 2 * SPB) * (2 * (size_t)(WIN ? BM + 8 : BM) * CV_ROW + 2 * (size_t)(NF * 16) * CV_ROW);
     const size_t stage = (size_t)(NT / 64) * 16 * ((NF / WN) * 16 + 4) * 4;
     return tiles > stage ? tiles : stage;
 }
 
-template <int NF, int WN, int BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, bool WIN = false>
+template <int NF, int WN, int BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, int WIN = 0>
 static hipError_t launch_conv_nf(const ConvParams& p, hipStream_t s) {
     const dim3 grid((unsigned)((p.rows + BM - 1) / BM), (unsigned)(p.cout_pad / (NF * 16))), block(NT);
     size_t lds = conv_lds_bytes<NF, WN, BM, SPB, NT, PP, WIN>();
@@ -583,21 +694,27 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
         }
         const bool win = p.tap_n > 1 && !(p.variant & 1);       // dev (MAGNET_CONV_VARIANT=1): one A stage per tap
         if (win && (p.variant & 4)) {                           // dev (MAGNET_CONV_VARIANT=4): 256-row tile, 8 waves, one workgroup per CU
-            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, false, true>(p, s);
-            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, false, true>(p, s);
-            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, false, true>(p, s);
+            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, false, 1>(p, s);
+            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, false, 1>(p, s);
+            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, false, 1>(p, s);
+        }
+        if (win && p.tap_n == 3 && !(p.variant & 8)) {          // dev (MAGNET_CONV_VARIANT=8): the 2-slot window loop below
+            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 128, 1, 1, 256, false, 2>(p, s);
+            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 128, 1, 8, 256, false, 2>(p, s);
+            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 128, 1, 9, 256, false, 2>(p, s);
         }
         if (win) {
-            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 128, 1, 1, 256, false, true>(p, s);
-            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 128, 1, 8, 256, false, true>(p, s);
-            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 128, 1, 9, 256, false, true>(p, s);
+            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 128, 1, 1, 256, false, 1>(p, s);
+            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 128, 1, 8, 256, false, 1>(p, s);
+            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 128, 1, 9, 256, false, 1>(p, s);
         }
         if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 128, 1, 1>(p, s);
         if (p.tail_cout == 128) return launch_conv_nf<8, 2, 128, 1, 8>(p, s);
         if (p.tail_cout == 144) return launch_conv_nf<8, 2, 128, 1, 9>(p, s);
         return hipErrorInvalidValue;
     }
-    if (p.cout_pad % 128 == 0 && p.tap_n > 1 && !(p.variant & 1) && !pp) return launch_conv_nf<8, 2, 128, 1, 0, 256, false, true>(p, s);
+    if (p.cout_pad % 128 == 0 && p.tap_n == 3 && !(p.variant & 9) && !pp) return launch_conv_nf<8, 2, 128, 1, 0, 256, false, 2>(p, s);
+    if (p.cout_pad % 128 == 0 && p.tap_n > 1 && !(p.variant & 1) && !pp) return launch_conv_nf<8, 2, 128, 1, 0, 256, false, 1>(p, s);
     if (p.cout_pad % 128 == 0 && pp) return launch_conv_nf<8, 2, 256, 1, 0, 512, true>(p, s);
     if (p.cout_pad % 128 == 0) return launch_conv_nf<8, 2, 128, 1>(p, s);
     if (p.cout_pad == 144) return launch_conv_nf<9, 1, 128, 1>(p, s);
