@@ -21,6 +21,7 @@
 // step; epilogue through LDS: bias, ReLU, then either re-split to bf16 hi/lo planes (input of the next layer)
 // or fp32 rows (last layer).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "../../include/magnet_hip.h"
 #include "conv_common.hpp"
@@ -903,8 +904,59 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
     }
 }
 
+// Wide variant (h*w % 4 == 0, C % 8 == 0): 128 pixels x 64 channels per workgroup, 8 independent 16-byte loads per thread
+// (512-byte runs along the pixel axis), tile rows of 132 floats with the pixel index XOR-swizzled in 4-word blocks by the channel
+// octet: the float4 tile writes and the transposed channel reads (8 lanes = one pixel's 8 octets) are both conflict-free.
+constexpr int PW_PIX = 128, PW_S = 132;
+__device__ __forceinline__ int pw_idx(int c, int q) { return c * PW_S + (q ^ (((c >> 3) & 7) << 2)); }
+__global__ __launch_bounds__(256) void pack_split_wide_kernel(const float* __restrict__ in, uint16_t* __restrict__ out_hi,
+                                                               uint16_t* __restrict__ out_lo, int C, int h, int w,
+                                                               int ctot, int c_off, long long in_img_stride) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * PW_S];
+    const int hw = h * w;
+    const int bpi = (hw + PW_PIX - 1) / PW_PIX;
+    const int n = blockIdx.x / bpi, p0 = (blockIdx.x % bpi) * PW_PIX, f0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, l4 = (tid & 31) * 4, cr = tid >> 5;          // 32 lanes x float4 = one channel row of the tile
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = cr + 8 * k, f = f0 + c, pp = p0 + l4;
+        v[k] = (pp < hw && f < C) ? *reinterpret_cast<const float4*>(in + (size_t)n * in_img_stride + (size_t)f * hw + pp)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(&tile[pw_idx(cr + 8 * k, l4)]) = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                          // 128 pixels x 8 octets
+        const int i = tid + it * 256;
+        const int q = i >> 3, vc = (i & 7) * 8, pq = p0 + q;
+        if (pq >= hw || f0 + vc >= C) continue;
+        const int y = pq / w, x = pq - y * w;
+        const size_t row = ((size_t)n * (h + 2) + (y + 1)) * (w + 2) + (x + 1);
+        uint32_t hh[4], ll[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint16_t h0, l0, h1, l1;
+            split_bf16(tile[pw_idx(vc + 2 * k, q)], h0, l0); split_bf16(tile[pw_idx(vc + 2 * k + 1, q)], h1, l1);
+            hh[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            ll[k] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        }
+        const size_t e = row * ctot + c_off + f0 + vc;
+        *reinterpret_cast<uint4*>(out_hi + e) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+        *reinterpret_cast<uint4*>(out_lo + e) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+    }
+}
+
 hipError_t launch_pack_split(const float* in, uint16_t* out_hi, uint16_t* out_lo, int N, int C, int h, int w,
                              int ctot, int c_off, long long in_img_stride, hipStream_t s) {
+    static const bool narrow = getenv("MAGNET_PACK_NARROW") != nullptr;      // dev A/B: the 64-pixel kernel
+    if (!narrow && (h * w) % 4 == 0 && C % 8 == 0 && in_img_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        const int bpw = (h * w + PW_PIX - 1) / PW_PIX;
+        hipLaunchKernelGGL(pack_split_wide_kernel, dim3((unsigned)(N * bpw), (unsigned)((C + 63) / 64)), dim3(256), 0, s, in, out_hi, out_lo,
+                           C, h, w, ctot, c_off, in_img_stride);
+        return hipGetLastError();
+    }
     const int bpi = (h * w + 63) / 64;
     const dim3 grid((unsigned)(N * bpi), (unsigned)((C + 63) / 64)), block(256);
     hipLaunchKernelGGL(pack_split_kernel, grid, block, 0, s, in, out_hi, out_lo, C, h, w, ctot, c_off, in_img_stride);

@@ -4,6 +4,7 @@
 //   upsample_depth : upsample_depth_via_mask (models/MAGNET.py:15-27)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "warp_math.hpp"
 
 namespace magnet {
@@ -45,6 +46,51 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ in,
                 w[k] = (uint32_t)f32_to_bf16_rne(tile[vc + 2 * k][q]) |
                        ((uint32_t)f32_to_bf16_rne(tile[vc + 2 * k + 1][q]) << 16);
             *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
+// Wide variant (hw % 4 == 0, F % 8 == 0): 128 pixels x 64 channels per workgroup, 8 independent 16-byte loads per thread, tile
+// rows of 132 floats with the pixel index XOR-swizzled in 4-word blocks by the channel octet (float4 tile writes and the
+// transposed reads are conflict-free).
+constexpr int PKW_PIX = 128, PKW_S = 132;
+__device__ __forceinline__ int pkw_idx(int c, int q) { return c * PKW_S + (q ^ (((c >> 3) & 7) << 2)); }
+template <typename OutT>
+__global__ __launch_bounds__(256) void pack_wide_kernel(const float* __restrict__ in, OutT* __restrict__ out,
+                                                         int F, int hw, int blocks_per_img, int w, int pad) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * PKW_S];
+    const int n = blockIdx.x / blocks_per_img;
+    const int p0 = (blockIdx.x % blocks_per_img) * PKW_PIX;
+    const int f0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, l4 = (tid & 31) * 4, cr = tid >> 5;
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int f = f0 + cr + 8 * k, pp = p0 + l4;
+        v[k] = (pp < hw && f < F) ? *reinterpret_cast<const float4*>(in + ((size_t)n * F + f) * hw + pp) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(&tile[pkw_idx(cr + 8 * k, l4)]) = v[k];
+    __syncthreads();
+    const int h_ = hw / w;
+    constexpr int VEC = 16 / sizeof(OutT);           // channels per 16-byte store
+    constexpr int VPP = 64 / VEC;                    // vectors per pixel (8 or 16)
+#pragma unroll
+    for (int it = 0; it < PKW_PIX * VPP / 256; ++it) {
+        const int i = tid + it * 256;
+        const int q = i / VPP, vc = (i % VPP) * VEC, pq = p0 + q;
+        if (pq >= hw || f0 + vc >= F) continue;
+        const int py = pq / w, px_ = pq - py * w;
+        const size_t tex = (size_t)n * (h_ + 2 * pad) * (w + 2 * pad) + (size_t)(py + pad) * (w + 2 * pad) + (px_ + pad);
+        OutT* dst = out + tex * F + f0 + vc;
+        if constexpr (sizeof(OutT) == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(tile[pkw_idx(vc, q)], tile[pkw_idx(vc + 1, q)], tile[pkw_idx(vc + 2, q)], tile[pkw_idx(vc + 3, q)]);
+        } else {
+            uint32_t wd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                wd[k] = (uint32_t)f32_to_bf16_rne(tile[pkw_idx(vc + 2 * k, q)]) | ((uint32_t)f32_to_bf16_rne(tile[pkw_idx(vc + 2 * k + 1, q)]) << 16);
+            *reinterpret_cast<uint4*>(dst) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
         }
     }
 }
@@ -100,6 +146,14 @@ hipError_t launch_pack(const float* in, void* out, int N, int F, int h, int w, b
         const size_t total = (size_t)N * (2 * (w + 2) + 2 * h) * vec_per_tex;
         const unsigned nb = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(zero_border_kernel, dim3(nb), dim3(256), 0, s, reinterpret_cast<uint4*>(out), N, h, w, vec_per_tex);
+    }
+    static const bool narrow = getenv("MAGNET_PACK_NARROW") != nullptr;      // dev A/B: the 64-pixel kernel
+    if (!narrow && hw % 4 == 0 && F % 8 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        const int bpw = (hw + PKW_PIX - 1) / PKW_PIX;
+        const dim3 gw((unsigned)(N * bpw), (unsigned)((F + 63) / 64));
+        if (bf16) hipLaunchKernelGGL((pack_wide_kernel<uint16_t>), gw, block, 0, s, in, (uint16_t*)out, F, hw, bpw, w, pad);
+        else      hipLaunchKernelGGL((pack_wide_kernel<float>),    gw, block, 0, s, in, (float*)out, F, hw, bpw, w, pad);
+        return hipGetLastError();
     }
     if (bf16) hipLaunchKernelGGL((pack_kernel<uint16_t, FT>), grid, block, 0, s, in, (uint16_t*)out, F, hw, bpi, w, pad);
     else      hipLaunchKernelGGL((pack_kernel<float, FT>),    grid, block, 0, s, in, (float*)out, F, hw, bpi, w, pad);
