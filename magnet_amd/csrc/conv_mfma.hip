@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include "../../include/magnet_hip.h"
 #include "conv_common.hpp"
+#include "warp_math.hpp"
 
 namespace magnet {
 
@@ -41,12 +42,7 @@ constexpr int CV_ROW = 64;                            // bytes per staged row (3
 // 80-byte padded rows: SQ_LDS_BANK_CONFLICT was 50 % of SQ_LDS_IDX_ACTIVE.
 __device__ __forceinline__ int cv_swz(int row, int slot) { return row * CV_ROW + ((slot ^ ((row >> 1) & 3)) << 4); }
 
-__device__ __forceinline__ uint16_t bf16_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+__device__ __forceinline__ uint16_t bf16_rne(float f) { return f32_to_bf16_rne(f); }     // v_cvt_pk_bf16_f32 (warp_math.hpp)
 __device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) {
     hi = bf16_rne(x);
     lo = bf16_rne(x - __uint_as_float((uint32_t)hi << 16));
@@ -105,12 +101,13 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
             const float4 b4 = *reinterpret_cast<const float4*>(bias + ch);
             float v[4] = {acc[n][m][0] + b4.x, acc[n][m][1] + b4.y, acc[n][m][2] + b4.z, acc[n][m][3] + b4.w};
             if constexpr (!LAST) {
-                uint16_t h[4], l[4];
+                uint32_t h01, l01, h23, l23;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = v[r] < 0.f ? 0.f : v[r]; split_bf16(v[r], h[r], l[r]); }
+                for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];
+                split_bf16x2(v[0], v[1], h01, l01); split_bf16x2(v[2], v[3], h23, l23);
                 const int off = act_swz(trow, ch >> 3) + (ch & 7) * 2;          // 8 bytes: channels ch..ch+3
-                *reinterpret_cast<uint2*>(act_hi + off) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-                *reinterpret_cast<uint2*>(act_lo + off) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+                *reinterpret_cast<uint2*>(act_hi + off) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(act_lo + off) = make_uint2(l01, l23);
             } else {
                 const long long row = row0 + trow;
                 if (row < rows) *reinterpret_cast<float4*>(out + (size_t)row * out_ld + ch) = make_float4(v[0], v[1], v[2], v[3]);
@@ -119,6 +116,93 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Column-owned form of the same layer (default): wave w computes output fragments n = w, w + 4 (32 of the 128 output channels)
+// for ALL rows of the tile, so it fetches a quarter of the layer's weights (16 KB instead of 64 KB per wave: with row ownership the
+// two resident workgroups pull 128 KB per K chunk through the CU's 64 B/clk vector-memory path for 1 536 cycles of MFMA work — the
+// tails ran at half the K loop's efficiency) and reads every row's activations from LDS (256 B/clk, cheap).  A remainder
+// fragment (TAILN % 4 == 1: the 16-channel G-Net head, the 9th fragment of the 144-channel mask head) is row-split over the
+// waves.  The layer's output replaces its input in place: one barrier after the last read, one after the last write.
+template <int TAILN, bool LAST, int ROWS>
+__device__ __forceinline__ void tail_layer_cols(const uint16_t* __restrict__ w_hi, const uint16_t* __restrict__ w_lo,
+                                                const float* __restrict__ bias, unsigned char* act_hi, unsigned char* act_lo,
+                                                float* __restrict__ out, int out_ld, long long row0, long long rows, int lane, int wv) {
+    constexpr int NJ = TAILN / 4, REM = TAILN % 4, MA = ROWS / 16, MR = MA / 4;      // MR: remainder-fragment row blocks per wave
+    static_assert(REM <= 1 && ROWS % 64 == 0, "one row-split remainder fragment at most");
+    f32x4_t acc[NJ > 0 ? NJ : 1][MA], accr[MR];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int m = 0; m < MA; ++m) acc[j][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < MR; ++m) accr[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, kslot = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        if constexpr (NJ > 0) {
+            bf16x8_t xh[MA], xl[MA];
+#pragma unroll
+            for (int m = 0; m < MA; ++m) {
+                xh[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_hi + act_swz(m * 16 + frow, kk * 4 + kslot)));
+                xl[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_lo + act_swz(m * 16 + frow, kk * 4 + kslot)));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const size_t e = (size_t)((wv + 4 * j) * 16 + frow) * 128 + kk * 32 + kslot * 8;
+                const bf16x8_t wh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_hi + e));
+                const bf16x8_t wl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_lo + e));
+#pragma unroll
+                for (int m = 0; m < MA; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[m], acc[j][m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MA; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[m], acc[j][m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MA; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[m], acc[j][m], 0, 0, 0);
+            }
+        }
+        if constexpr (REM) {
+            const size_t e = (size_t)(NJ * 4 * 16 + frow) * 128 + kk * 32 + kslot * 8;
+            const bf16x8_t wh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_hi + e));
+            const bf16x8_t wl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_lo + e));
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const int row = (wv * MR + m) * 16 + frow;
+                const bf16x8_t rh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_hi + act_swz(row, kk * 4 + kslot)));
+                const bf16x8_t rl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_lo + act_swz(row, kk * 4 + kslot)));
+                accr[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, rl, accr[m], 0, 0, 0);
+                accr[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, rh, accr[m], 0, 0, 0);
+                accr[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, rh, accr[m], 0, 0, 0);
+            }
+        }
+    }
+    if constexpr (!LAST) __syncthreads();                     // every wave is done reading the layer's input: overwrite it in place
+    auto emit = [&](const f32x4_t& a, int n, int mrow) {
+        const int ch = n * 16 + (lane >> 4) * 4;
+        const int trow = mrow * 16 + (lane & 15);
+        const float4 b4 = *reinterpret_cast<const float4*>(bias + ch);
+        float v[4] = {a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w};
+        if constexpr (!LAST) {
+            uint32_t h01, l01, h23, l23;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];
+            split_bf16x2(v[0], v[1], h01, l01); split_bf16x2(v[2], v[3], h23, l23);
+            const int off = act_swz(trow, ch >> 3) + (ch & 7) * 2;              // 8 bytes: channels ch..ch+3
+            *reinterpret_cast<uint2*>(act_hi + off) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(act_lo + off) = make_uint2(l01, l23);
+        } else {
+            const long long row = row0 + trow;
+            if (row < rows) *reinterpret_cast<float4*>(out + (size_t)row * out_ld + ch) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int m = 0; m < MA; ++m) emit(acc[j][m], wv + 4 * j, m);
+    if constexpr (REM) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) emit(accr[m], NJ * 4, wv * MR + m);
+    }
+    if constexpr (!LAST) __syncthreads();
 }
 
 // TAIL = 0: plain layer.  TAIL = 16-column fragments of the fused tail's last layer (1, 8 or 9): see ConvParams::tail_*.
@@ -557,6 +641,16 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
                     *reinterpret_cast<uint16_t*>(act_lo + off) = l;
                 }
         __syncthreads();
+        if constexpr (NT == 256 && CV_BM == 128) {
+            if (!(p.variant & 32)) {                          // dev (MAGNET_CONV_VARIANT=32): the row-owned tail below
+                tail_layer_cols<8, false, CV_BM>(p.tail_w_hi, p.tail_w_lo, p.tail_bias, act_hi, act_lo, nullptr, 0, row0, p.rows, lane, wv);
+                tail_layer_cols<8, false, CV_BM>(p.tail_w_hi + 128 * 128, p.tail_w_lo + 128 * 128, p.tail_bias + 128, act_hi, act_lo, nullptr, 0,
+                                                 row0, p.rows, lane, wv);
+                tail_layer_cols<TAIL, true, CV_BM>(p.tail_w_hi + 2 * 128 * 128, p.tail_w_lo + 2 * 128 * 128, p.tail_bias + 256, act_hi, act_lo,
+                                                   p.out_f32, p.tail_cout, row0, p.rows, lane, wv);
+                return;
+            }
+        }
         tail_layer<8, false>(p.tail_w_hi, p.tail_w_lo, p.tail_bias, act_hi, act_lo, nullptr, 0, row0, p.rows, lane, wv);
         tail_layer<8, false>(p.tail_w_hi + 128 * 128, p.tail_w_lo + 128 * 128, p.tail_bias + 128, act_hi, act_lo, nullptr, 0, row0,
                              p.rows, lane, wv);
@@ -634,17 +728,12 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
             if (p.out_mode == 2) {                            // single bf16 plane (RNE): the matcher's bf16 feature storage
                 uint32_t h[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) h[i] = (uint32_t)bf16_rne(v[2 * i]) | ((uint32_t)bf16_rne(v[2 * i + 1]) << 16);
+                for (int i = 0; i < 4; ++i) h[i] = f32x2_to_bf16x2_rne(v[2 * i], v[2 * i + 1]);
                 *reinterpret_cast<uint4*>(p.out_hi + e) = make_uint4(h[0], h[1], h[2], h[3]);
             } else if (p.out_mode == 0) {
                 uint32_t h[4], l[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint16_t h0, l0, h1, l1;
-                    split_bf16(v[2 * i], h0, l0); split_bf16(v[2 * i + 1], h1, l1);
-                    h[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                    l[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
-                }
+                for (int i = 0; i < 4; ++i) split_bf16x2(v[2 * i], v[2 * i + 1], h[i], l[i]);
                 *reinterpret_cast<uint4*>(p.out_hi + e) = make_uint4(h[0], h[1], h[2], h[3]);
                 *reinterpret_cast<uint4*>(p.out_lo + e) = make_uint4(l[0], l[1], l[2], l[3]);
             } else {
@@ -817,12 +906,13 @@ __device__ __forceinline__ void chain_layer(const ChainParams& p, const uint16_t
             const float4 b4 = *reinterpret_cast<const float4*>(bias + ch);
             float v[4] = {acc[n][m][0] + b4.x, acc[n][m][1] + b4.y, acc[n][m][2] + b4.z, acc[n][m][3] + b4.w};
             if constexpr (!LAST) {
-                uint16_t h[4], l[4];
+                uint32_t h01, l01, h23, l23;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = v[r] < 0.f ? 0.f : v[r]; split_bf16(v[r], h[r], l[r]); }
+                for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];
+                split_bf16x2(v[0], v[1], h01, l01); split_bf16x2(v[2], v[3], h23, l23);
                 const int off = act_swz(trow, ch >> 3) + (ch & 7) * 2;          // 8 bytes: channels ch..ch+3
-                *reinterpret_cast<uint2*>(act_hi + off) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-                *reinterpret_cast<uint2*>(act_lo + off) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+                *reinterpret_cast<uint2*>(act_hi + off) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(act_lo + off) = make_uint2(l01, l23);
             } else {
                 const long long row = row0 + trow;
                 if (row < p.rows)
@@ -893,10 +983,7 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
         uint32_t hh[4], ll[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint16_t h0, l0, h1, l1;
-            split_bf16(tile[vc + 2 * k][q], h0, l0); split_bf16(tile[vc + 2 * k + 1][q], h1, l1);
-            hh[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            ll[k] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+            split_bf16x2(tile[vc + 2 * k][q], tile[vc + 2 * k + 1][q], hh[k], ll[k]);
         }
         const size_t e = row * ctot + c_off + f0 + vc;
         *reinterpret_cast<uint4*>(out_hi + e) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
@@ -937,10 +1024,7 @@ __global__ __launch_bounds__(256) void pack_split_wide_kernel(const float* __res
         uint32_t hh[4], ll[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint16_t h0, l0, h1, l1;
-            split_bf16(tile[pw_idx(vc + 2 * k, q)], h0, l0); split_bf16(tile[pw_idx(vc + 2 * k + 1, q)], h1, l1);
-            hh[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            ll[k] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+            split_bf16x2(tile[pw_idx(vc + 2 * k, q)], tile[pw_idx(vc + 2 * k + 1, q)], hh[k], ll[k]);
         }
         const size_t e = row * ctot + c_off + f0 + vc;
         *reinterpret_cast<uint4*>(out_hi + e) = make_uint4(hh[0], hh[1], hh[2], hh[3]);

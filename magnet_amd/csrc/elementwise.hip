@@ -43,8 +43,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ in,
             uint32_t w[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                w[k] = (uint32_t)f32_to_bf16_rne(tile[vc + 2 * k][q]) |
-                       ((uint32_t)f32_to_bf16_rne(tile[vc + 2 * k + 1][q]) << 16);
+                w[k] = f32x2_to_bf16x2_rne(tile[vc + 2 * k][q], tile[vc + 2 * k + 1][q]);
             *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(256) void pack_wide_kernel(const float* __restrict_
             uint32_t wd[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                wd[k] = (uint32_t)f32_to_bf16_rne(tile[pkw_idx(vc + 2 * k, q)]) | ((uint32_t)f32_to_bf16_rne(tile[pkw_idx(vc + 2 * k + 1, q)]) << 16);
+                wd[k] = f32x2_to_bf16x2_rne(tile[pkw_idx(vc + 2 * k, q)], tile[pkw_idx(vc + 2 * k + 1, q)]);
             *reinterpret_cast<uint4*>(dst) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
         }
     }
