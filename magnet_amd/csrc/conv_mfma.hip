@@ -205,6 +205,15 @@ __device__ __forceinline__ void tail_layer_cols(const uint16_t* __restrict__ w_h
     if constexpr (!LAST) __syncthreads();
 }
 
+// One MFMA of the K loop.  SWAP (kernels with a fused tail): operands exchanged, so the accumulator holds C^T — a lane has 4
+// consecutive output CHANNELS of one row, and the tail's activation tile is written with packed conversions and 8-byte LDS stores
+// (the plain orientation gives 4 consecutive rows of one channel: 128 two-byte stores per lane and tile).
+template <bool SWAP>
+__device__ __forceinline__ f32x4_t cv_mma(const bf16x8_t& a, const bf16x8_t& b, const f32x4_t& c) {
+    if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // TAIL = 0: plain layer.  TAIL = 16-column fragments of the fused tail's last layer (1, 8 or 9): see ConvParams::tail_*.
 // PP = "ping-pong" K loop: NT = 512 threads = 8 waves = two wave groups (waves 0-3 / 4-7: one wave of each group per SIMD) that
 // run the same program half a K step apart — while one group issues its fragment reads and the LDS-DMA of the stage two steps
@@ -340,11 +349,11 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
             // term-major order: consecutive MFMAs write DIFFERENT accumulators (a dependent MFMA on the same
             // accumulator waits out the full pipeline latency); small terms first
 #pragma unroll
-            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh, acc[m][n], 0, 0, 0);
+            for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(al[m], bh, acc[m][n]);
 #pragma unroll
-            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
+            for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(ah[m], bl, acc[m][n]);
 #pragma unroll
-            for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
+            for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(ah[m], bh, acc[m][n]);
         }
     };
 
@@ -410,11 +419,11 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
             for (int n = 0; n < NFW; ++n) {
                 const bf16x8_t bh = fbh[n], bl = fbl[n];
 #pragma unroll
-                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[m], bh, acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xl[m], bh, acc[m][n]);
 #pragma unroll
-                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[m], bl, acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xh[m], bl, acc[m][n]);
 #pragma unroll
-                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[m], bh, acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xh[m], bh, acc[m][n]);
             }
         };
 #define CV_WAIT_BARRIER(N)                                                                     \
@@ -506,11 +515,11 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
                 const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
                 const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_lo + b_off + n * 16 * CV_ROW));
 #pragma unroll
-                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh, acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(al[m], bh, acc[m][n]);
 #pragma unroll
-                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(ah[m], bl, acc[m][n]);
 #pragma unroll
-                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(ah[m], bh, acc[m][n]);
             }
         };
         dma_a(0);
@@ -582,11 +591,11 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int n = 0; n < NFW; ++n) {
 #pragma unroll
-                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[m], fbh[n], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(fal[m], fbh[n], acc[m][n]);
 #pragma unroll
-                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[m], fbl[n], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(fah[m], fbl[n], acc[m][n]);
 #pragma unroll
-                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[m], fbh[n], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(fah[m], fbh[n], acc[m][n]);
             }
             __builtin_amdgcn_s_setprio(0);
             asm volatile("" ::: "memory");
@@ -622,24 +631,27 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
         for (int m = 0; m < MF; ++m)
 #pragma unroll
-            for (int n = 0; n < NFW; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int trow = wm * (MF * 16) + m * 16 + (lane >> 4) * 4 + r;
-                    const int ch = wn * (NFW * 16) + n * 16 + (lane & 15);
-                    float x = acc[m][n][r];
-                    if (p.addend) {
-                        const long long row = row0 + trow;
-                        x += p.addend[(size_t)(row < p.rows ? row : p.rows - 1) * p.addend_ld + ch];
-                    }
-                    x += p.bias[ch];
-                    x = (p.relu && x < 0.f) ? 0.f : x;
-                    uint16_t h, l;
-                    split_bf16(x, h, l);
-                    const int off = act_swz(trow, ch >> 3) + (ch & 7) * 2;
-                    *reinterpret_cast<uint16_t*>(act_hi + off) = h;
-                    *reinterpret_cast<uint16_t*>(act_lo + off) = l;
+            for (int n = 0; n < NFW; ++n) {                   // C^T accumulators (cv_mma<true>): 4 consecutive channels of one row
+                const int trow = wm * (MF * 16) + m * 16 + (lane & 15);
+                const int ch = wn * (NFW * 16) + n * 16 + (lane >> 4) * 4;
+                float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+                if (p.addend) {                               // (acc + addend) + bias: the order of the plain epilogue
+                    const long long row = row0 + trow;
+                    const float4 a4 = *reinterpret_cast<const float4*>(p.addend + (size_t)(row < p.rows ? row : p.rows - 1) * p.addend_ld + ch);
+                    v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
                 }
+                const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch);
+                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                if (p.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];
+                }
+                uint32_t h01, l01, h23, l23;
+                split_bf16x2(v[0], v[1], h01, l01); split_bf16x2(v[2], v[3], h23, l23);
+                const int off = act_swz(trow, ch >> 3) + (ch & 7) * 2;
+                *reinterpret_cast<uint2*>(act_hi + off) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(act_lo + off) = make_uint2(l01, l23);
+            }
         __syncthreads();
         if constexpr (NT == 256 && CV_BM == 128) {
             if (!(p.variant & 32)) {                          // dev (MAGNET_CONV_VARIANT=32): the row-owned tail below
