@@ -823,6 +823,10 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
     if (p.cout_pad == 16)  return launch_conv_nf<1, 1, 128, 1>(p, s);
     // F-Net trunk widths: 4 waves stacked along M.  Measured on the whole F-Net (40 images, 23.5 ms): 256-row tiles for
     // the 32- / 64-wide layers 24.1 / 24.2 ms, 192-row tile for 64-wide 24.6 ms, 2x2 waves for 64-wide 23.6 ms — no better.
+    // 64-wide 3x3 layers of the trunk: the register-window loop too (their A operand is 2/3 of the DMA pieces of a K step;
+    // the 32-wide ones would need per-wave vmcnt counts: only two of the four waves stage weight rows); dev
+    // (MAGNET_CONV_VARIANT=8): one A stage per tap
+    if (p.cout_pad == 64 && p.tap_n == 3 && !(p.variant & 9))  return launch_conv_nf<4, 1, 128, 1, 0, 256, false, 2>(p, s);
     if (p.cout_pad == 32)  return launch_conv_nf<2, 1, 128, 1>(p, s);
     if (p.cout_pad == 64)  return launch_conv_nf<4, 1, 128, 1>(p, s);
     return hipErrorInvalidValue;
