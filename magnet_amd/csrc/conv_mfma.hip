@@ -362,7 +362,7 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
         // (read once per group), so one LDS window slot suffices and the weight tiles get a 3-slot ring: stage s+2's LDS-DMA is
         // issued right after the barrier of sub-step s and stays in flight across two barriers behind counted s_waitcnt vmcnt
         // (loads retire in order: "all but the pieces issued in the previous sub-step" = stage s landed).  Issuing the pieces
-        // later in the sub-step, between the MFMAs, was measured 2.5 % slower (same box A/B).  3 sub-steps per
+        // later in the sub-step, between the MFMAs, was measured 2.5 % slower, s_setprio around the MFMA block 1 % slower (same box A/B).  3 sub-steps per
         // group and 3 slots: stage s = 3g + tx lives in slot tx — every LDS address below is static.
         static_assert(!PP && SPB == 1 && NT == 256 && BN % RP == 0, "window loop with register-resident A: 4 waves, whole DMA passes");
         // Measured and rejected: the same loop with a 2-slot weight ring and a two-pass (2 x 64 rows) fused tail so that THREE
