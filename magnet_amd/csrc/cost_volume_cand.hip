@@ -108,7 +108,6 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
     for (int e = lane; e < 16 * p.V; e += 64) {
         const int q = e & 15, v = e >> 4;
         const int xc = min(x_base + q, p.w - 1);
-        const size_t pix = (size_t)yc * p.w + xc;
         float r0, r1, r2;
         load_ray(p, b, hw, xc, yc, r0, r1, r2);
         const PixelView pv = make_pixel_view(p.intM + (size_t)b * 9, p.poses + ((size_t)b * p.V + v) * 16, r0, r1, r2);

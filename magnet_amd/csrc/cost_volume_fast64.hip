@@ -63,7 +63,6 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
     for (int e = lane; e < NPX * p.V; e += 64) {
         const int q = e % NPX, v = e / NPX;
         const int xc = min(x_base + q, p.w - 1);
-        const size_t pix = (size_t)yc * p.w + xc;
         float r0, r1, r2;
         load_ray(p, b, hw, xc, yc, r0, r1, r2);
         const PixelView pv = make_pixel_view(p.intM + (size_t)b * 9, p.poses + ((size_t)b * p.V + v) * 16, r0, r1, r2);
@@ -76,7 +75,6 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
     const uint32_t texel_bytes = (uint32_t)p.F * (uint32_t)sizeof(FeatT);
     const int nchunk = (int)(texel_bytes / 16);
     const uint32_t xlim = __float_as_uint((float)(p.w + 1)), ylim = __float_as_uint((float)(p.h + 1));   // see cost_volume_fast.hip
-    const float fwc = (float)p.w, fhc = (float)p.h;
     const int j0 = lane;
     const int sub = lane & (LPU - 1), tap = (lane / LPU) & 3, upair = lane / (4 * LPU);          // correlation: chunk, tap, item of the pass
     const uint32_t lane_src_off = (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes + (uint32_t)sub * 16u;
