@@ -433,6 +433,12 @@ def test_full_step_bench_size_batch_invariance(hip_lib, gpu):
     with torch.no_grad():
         full = model.match_and_refine(inp["ref_gmms"], x_d3, inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"],
                                       inp["is_valid"], inp["cam_intrins"], mode="test")[-1].clone()
+        # run-to-run: every kernel of the step sums in a fixed order and the LDS-DMA rings are ordered by counted waits + barriers,
+        # so a second pass over the same inputs is bit-identical everywhere (a rare staging race would show up here)
+        for _ in range(2):
+            again = model.match_and_refine(inp["ref_gmms"], x_d3, inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"],
+                                           inp["is_valid"], inp["cam_intrins"], mode="test")[-1]
+            assert torch.equal(again, full)
     V = wl.V
     for b in (0, 63):
         sel = lambda t: t[b:b + 1].contiguous()
