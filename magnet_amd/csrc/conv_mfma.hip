@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/magnet_hip.h"
 #include "conv_common.hpp"
 #include "warp_math.hpp"
@@ -124,12 +125,13 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
 // tails ran at half the K loop's efficiency) and reads every row's activations from LDS (256 B/clk, cheap).  A remainder
 // fragment (TAILN % 4 == 1: the 16-channel G-Net head, the 9th fragment of the 144-channel mask head) is row-split over the
 // waves.  The layer's output replaces its input in place: one barrier after the last read, one after the last write.
-template <int TAILN, bool LAST, int ROWS>
+template <int TAILN, bool LAST, int ROWS, int NW = 4>
 __device__ __forceinline__ void tail_layer_cols(const uint16_t* __restrict__ w_hi, const uint16_t* __restrict__ w_lo,
                                                 const float* __restrict__ bias, unsigned char* act_hi, unsigned char* act_lo,
                                                 float* __restrict__ out, int out_ld, long long row0, long long rows, int lane, int wv) {
-    constexpr int NJ = TAILN / 4, REM = TAILN % 4, MA = ROWS / 16, MR = MA / 4;      // MR: remainder-fragment row blocks per wave
-    static_assert(REM <= 1 && ROWS % 64 == 0, "one row-split remainder fragment at most");
+    // NW waves: wave w owns output fragments w, w + NW, ...; MA row blocks, read from LDS 8 at a time
+    constexpr int NJ = TAILN / NW, REM = TAILN % NW, MA = ROWS / 16, MR = MA / NW;   // MR: remainder-fragment row blocks per wave
+    static_assert(REM <= 1 && MA % 8 == 0 && MA % NW == 0, "one row-split remainder fragment at most");
     f32x4_t acc[NJ > 0 ? NJ : 1][MA], accr[MR];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -141,27 +143,34 @@ __device__ __forceinline__ void tail_layer_cols(const uint16_t* __restrict__ w_h
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         if constexpr (NJ > 0) {
-            bf16x8_t xh[MA], xl[MA];
-#pragma unroll
-            for (int m = 0; m < MA; ++m) {
-                xh[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_hi + act_swz(m * 16 + frow, kk * 4 + kslot)));
-                xl[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_lo + act_swz(m * 16 + frow, kk * 4 + kslot)));
-            }
+            bf16x8_t wh[NJ], wl[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const size_t e = (size_t)((wv + 4 * j) * 16 + frow) * 128 + kk * 32 + kslot * 8;
-                const bf16x8_t wh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_hi + e));
-                const bf16x8_t wl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_lo + e));
+                const size_t e = (size_t)((wv + NW * j) * 16 + frow) * 128 + kk * 32 + kslot * 8;
+                wh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_hi + e));
+                wl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_lo + e));
+            }
 #pragma unroll
-                for (int m = 0; m < MA; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[m], acc[j][m], 0, 0, 0);
+            for (int mb = 0; mb < MA; mb += 8) {
+                bf16x8_t xh[8], xl[8];
 #pragma unroll
-                for (int m = 0; m < MA; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[m], acc[j][m], 0, 0, 0);
+                for (int m = 0; m < 8; ++m) {
+                    xh[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_hi + act_swz((mb + m) * 16 + frow, kk * 4 + kslot)));
+                    xl[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(act_lo + act_swz((mb + m) * 16 + frow, kk * 4 + kslot)));
+                }
 #pragma unroll
-                for (int m = 0; m < MA; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[m], acc[j][m], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) acc[j][mb + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xl[m], acc[j][mb + m], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) acc[j][mb + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], xh[m], acc[j][mb + m], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) acc[j][mb + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xh[m], acc[j][mb + m], 0, 0, 0);
+                }
             }
         }
         if constexpr (REM) {
-            const size_t e = (size_t)(NJ * 4 * 16 + frow) * 128 + kk * 32 + kslot * 8;
+            const size_t e = (size_t)(NJ * NW * 16 + frow) * 128 + kk * 32 + kslot * 8;
             const bf16x8_t wh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_hi + e));
             const bf16x8_t wl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w_lo + e));
 #pragma unroll
@@ -197,10 +206,10 @@ __device__ __forceinline__ void tail_layer_cols(const uint16_t* __restrict__ w_h
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int m = 0; m < MA; ++m) emit(acc[j][m], wv + 4 * j, m);
+        for (int m = 0; m < MA; ++m) emit(acc[j][m], wv + NW * j, m);
     if constexpr (REM) {
 #pragma unroll
-        for (int m = 0; m < MR; ++m) emit(accr[m], NJ * 4, wv * MR + m);
+        for (int m = 0; m < MR; ++m) emit(accr[m], NJ * NW, wv * MR + m);
     }
     if constexpr (!LAST) __syncthreads();
 }
@@ -357,6 +366,359 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
         }
     };
 
+    if constexpr (WIN == 3 && PP) {
+        // ---- ping-pong x LDS window x fragment double-buffering (dev, MAGNET_CONV_VARIANT=128): the fragments of sub-step s+1 are read
+        // at the START of the compute phase of sub-step s into a second register set (in the shadow of the 48 MFMAs), so a LOAD phase
+        // is only DMA issue + counted wait + barrier.  That needs every stage visible one phase earlier: 4-slot weight ring (DMA
+        // distance 3), 2-slot window filled at tx = 0 of the previous group.  With the groups staggered by one barrier:
+        //   L_s: [tx = 0: DMA window g+1 -> slot (g+1)&1]  DMA weights s+3 -> slot (s+3)&3;  vmcnt(pieces of THIS phase);  barrier
+        //   C_s: ds_read fragments of sub-step s+1 (window g' = (s+1)/3, weights slot (s+1)&3);  48 MFMAs of sub-step s;  lgkmcnt(0);  barrier
+        // RAW: what L_{s-1}'s waits retired (weights s+1, window parts issued at or before L_{s-2}) has passed both groups' waits and
+        // a barrier when C_s starts.  WAR: slot (s+3)&3 held stage s-1, read at the start of C_{s-2} and retired before the barrier
+        // that ends it; the window slot of g+1 held window g-1, last read at the start of C_{3g-2}.
+        static_assert(NT == 512 && SPB == 1 && BN % RP == 0 && CV_BM % RP == 0, "8 waves, whole DMA passes");
+        constexpr int BP = 2 * B_PT, AP = 2 * A_PT;
+        unsigned char* const a_ring = smem;                   // 2 x [hi | lo]
+        unsigned char* const b_ring = smem + 4 * A_BYTES;     // 4 x [hi | lo]
+        const int aw = CV_BM + 2 * p.tap_sx;
+        const int ngroups = 3 * ksteps_per_tap;               // even (checked by the launcher)
+        const int nsub = 3 * ngroups;
+        int g_ty = 0, g_k0 = 0, bs_tap = 0, bs_k0 = 0;
+        auto dma_a = [&](int slot) {
+            unsigned char* sa_hi = a_ring + slot * (2 * A_BYTES);
+            unsigned char* sa_lo = sa_hi + A_BYTES;
+            const int a_u = (((g_ty + p.tap_o0) * p.tap_sy + p.tap_o0 * p.tap_sx) * p.in_ld + g_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < A_PT; ++i) {
+                CV_BLDS(ra_hi, sa_hi + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+                CV_BLDS(ra_lo, sa_lo + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+            }
+            if (wv == 0 && st_r < aw - CV_BM) {
+                const int ax = a_v[0] + CV_BM * p.in_ld * 2;
+                CV_BLDS(ra_hi, sa_hi + CV_BM * CV_ROW, ax + a_u);
+                CV_BLDS(ra_lo, sa_lo + CV_BM * CV_ROW, ax + a_u);
+            }
+            if (++g_ty == 3) { g_ty = 0; g_k0 += CV_BK; }
+        };
+        auto dma_b = [&](int slot) {
+            unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
+            unsigned char* sb_lo = sb_hi + B_BYTES;
+            const int b_u = (bs_tap * p.cout_pad * p.cin + bs_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < B_PT; ++i) {
+                CV_BLDS(rb_hi, sb_hi + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+                CV_BLDS(rb_lo, sb_lo + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+            }
+            if (++bs_tap == 9) { bs_tap = 0; bs_k0 += CV_BK; }
+        };
+        int a_offx[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) a_offx[tx] = cv_swz(wm * (MF * 16) + frow + tx * p.tap_sx, lane >> 4);
+        bf16x8_t xah0[MF], xal0[MF], xbh0[NFW], xbl0[NFW], xah1[MF], xal1[MF], xbh1[NFW], xbl1[NFW];
+        auto read_frags = [&](bf16x8_t (&fa_h)[MF], bf16x8_t (&fa_l)[MF], bf16x8_t (&fb_h)[NFW], bf16x8_t (&fb_l)[NFW], int aslot, int a_of, int bslot) {
+            const unsigned char* sa_hi = a_ring + aslot * (2 * A_BYTES);
+            const unsigned char* sb_hi = b_ring + bslot * (2 * B_BYTES);
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+                fb_h[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
+                fb_l[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + B_BYTES + b_off + n * 16 * CV_ROW));
+            }
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                fa_h[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa_hi + a_of + m * 16 * CV_ROW));
+                fa_l[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sa_hi + A_BYTES + a_of + m * 16 * CV_ROW));
+            }
+        };
+        int sidx = 0;                                         // sub-step counter
+        // one sub-step: TX static, (c*) = fragments of this sub-step, (n*) = register set filled for the next one
+        auto substep = [&](auto TXc, int gslot, bool lastg, bf16x8_t (&ca_h)[MF], bf16x8_t (&ca_l)[MF], bf16x8_t (&cb_h)[NFW], bf16x8_t (&cb_l)[NFW],
+                           bf16x8_t (&na_h)[MF], bf16x8_t (&na_l)[MF], bf16x8_t (&nb_h)[NFW], bf16x8_t (&nb_l)[NFW]) {
+            constexpr int TX = decltype(TXc)::value;
+            // ---- LOAD phase ----
+            asm volatile("" ::: "memory");
+            if (!lastg) {
+                dma_b((sidx + 3) & 3);
+                if constexpr (TX == 0) {
+                    dma_a(gslot ^ 1);
+                    if (wv == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BP + AP + 2) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BP + AP) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BP) : "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            // ---- COMPUTE phase ----
+            asm volatile("" ::: "memory");
+            if (sidx + 1 < nsub)
+                read_frags(na_h, na_l, nb_h, nb_l, TX == 2 ? (gslot ^ 1) : gslot, a_offx[(TX + 1) % 3], (sidx + 1) & 3);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(ca_l[m], cb_h[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(ca_h[m], cb_l[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(ca_h[m], cb_h[n], acc[m][n]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            ++sidx;
+        };
+        const int grp = __builtin_amdgcn_readfirstlane(wv >> 2);
+        dma_a(0);
+        dma_b(0); dma_b(1); dma_b(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(xah0, xal0, xbh0, xbl0, 0, a_offx[0], 0);
+        if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier (= half a sub-step) behind group 0
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        for (int g = 0; g < ngroups; g += 2) {
+            const bool last2 = g + 2 == ngroups;
+            substep(I0{}, 0, false, xah0, xal0, xbh0, xbl0, xah1, xal1, xbh1, xbl1);
+            substep(I1{}, 0, false, xah1, xal1, xbh1, xbl1, xah0, xal0, xbh0, xbl0);
+            substep(I2{}, 0, false, xah0, xal0, xbh0, xbl0, xah1, xal1, xbh1, xbl1);
+            substep(I0{}, 1, last2, xah1, xal1, xbh1, xbl1, xah0, xal0, xbh0, xbl0);
+            substep(I1{}, 1, last2, xah0, xal0, xbh0, xbl0, xah1, xal1, xbh1, xbl1);
+            substep(I2{}, 1, last2, xah1, xal1, xbh1, xbl1, xah0, xal0, xbh0, xbl0);
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();           // balance group 1's extra barrier
+        __syncthreads();                                      // nothing in flight; the ring is dead
+    } else
+    if constexpr (WIN == 1 && PP) {
+        // ---- ping-pong x LDS window (dev, MAGNET_CONV_VARIANT=64): as the register-window ping-pong loop below, but the window has
+        // two LDS slots (one workgroup per CU: 117 KB), so its DMA is spread over tx = 0 / 1 and every LOAD phase is the same 16
+        // fragment reads + 2 - 4 DMA pieces.  Phase order per group: L_s = reads of stage
+        // s, DMA of stage s+2 (and of window g+1 at tx = 1), counted vmcnt for everything older, lgkmcnt(0), barrier; C_s = MFMAs,
+        // barrier.  RAW: a stage is read one L phase after every wave's wait for it and a barrier both groups passed; WAR: a
+        // slot is refilled in the L phase after the one whose reads of it retired before a barrier both groups passed.
+        static_assert(NT == 512 && SPB == 1 && BN % RP == 0 && CV_BM % RP == 0, "8 waves, whole DMA passes");
+        constexpr int BP = 2 * B_PT, AP = 2 * A_PT;
+        unsigned char* const a_ring = smem;                   // 2 x [hi | lo]
+        unsigned char* const b_ring = smem + 4 * A_BYTES;
+        const int aw = CV_BM + 2 * p.tap_sx;
+        const int ngroups = 3 * ksteps_per_tap;
+        int g_ty = 0, g_k0 = 0, bs_tap = 0, bs_k0 = 0;
+        // window g + 1 -> slot (g + 1) & 1 in two parts: part 0 = first row pass + the rows past the tile, part 1 = second row pass
+        auto dma_a = [&](int slot, int part) {
+            unsigned char* sa_hi = a_ring + slot * (2 * A_BYTES);
+            unsigned char* sa_lo = sa_hi + A_BYTES;
+            const int a_u = (((g_ty + p.tap_o0) * p.tap_sy + p.tap_o0 * p.tap_sx) * p.in_ld + g_k0) * 2;
+            CV_BLDS(ra_hi, sa_hi + (wave_row + part * RP) * CV_ROW, a_v[part] + a_u);
+            CV_BLDS(ra_lo, sa_lo + (wave_row + part * RP) * CV_ROW, a_v[part] + a_u);
+            if (part == 0) {
+                if (wv == 0 && st_r < aw - CV_BM) {
+                    const int ax = a_v[0] + CV_BM * p.in_ld * 2;
+                    CV_BLDS(ra_hi, sa_hi + CV_BM * CV_ROW, ax + a_u);
+                    CV_BLDS(ra_lo, sa_lo + CV_BM * CV_ROW, ax + a_u);
+                }
+            } else if (++g_ty == 3) { g_ty = 0; g_k0 += CV_BK; }
+        };
+        auto dma_b = [&](int slot) {
+            unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
+            unsigned char* sb_lo = sb_hi + B_BYTES;
+            const int b_u = (bs_tap * p.cout_pad * p.cin + bs_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < B_PT; ++i) {
+                CV_BLDS(rb_hi, sb_hi + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+                CV_BLDS(rb_lo, sb_lo + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+            }
+            if (++bs_tap == 9) { bs_tap = 0; bs_k0 += CV_BK; }
+        };
+        int a_offx[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) a_offx[tx] = cv_swz(wm * (MF * 16) + frow + tx * p.tap_sx, lane >> 4);
+        static_assert(A_PT == 2, "two window row passes");
+        bf16x8_t ah[MF], al[MF], fbh[NFW], fbl[NFW];
+        auto load_a = [&](int slot, int a_of) {
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                ah[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_ring + slot * (2 * A_BYTES) + a_of + m * 16 * CV_ROW));
+                al[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_ring + slot * (2 * A_BYTES) + A_BYTES + a_of + m * 16 * CV_ROW));
+            }
+        };
+        auto load_b = [&](int slot) {
+            const unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
+            const unsigned char* sb_lo = sb_hi + B_BYTES;
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+                fbh[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
+                fbl[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_lo + b_off + n * 16 * CV_ROW));
+            }
+        };
+        auto mfmas = [&](const bf16x8_t (&xh)[MF], const bf16x8_t (&xl)[MF]) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xl[m], fbh[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xh[m], fbl[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xh[m], fbh[n], acc[m][n]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+#define CV_END_LOAD(N)                                                                         \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");                    \
+        __builtin_amdgcn_s_barrier();
+        const int grp = __builtin_amdgcn_readfirstlane(wv >> 2);
+        dma_a(0, 0); dma_a(0, 1);
+        dma_b(0);
+        dma_b(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BP) : "memory");                 // window 0 and stage 0 landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier (= half a sub-step) behind group 0
+        for (int g = 0; g < ngroups; ++g) {
+            const bool lastg = g + 1 == ngroups;
+            const int as = g & 1;
+            // ---- tx = 0 ----
+            asm volatile("" ::: "memory");
+            load_a(as, a_offx[0]);
+            load_b(0);
+            dma_b(2);                                         // stage 3g + 2
+            if (!lastg) {
+                dma_a(as ^ 1, 0);                             // window g + 1, first part (its slot was last read in group g - 1)
+                if (wv == 0) { CV_END_LOAD(BP + 4) } else { CV_END_LOAD(BP + 2) }            // stage 3g + 1 landed
+            } else { CV_END_LOAD(BP) }
+            mfmas(ah, al);
+            // ---- tx = 1 ----
+            asm volatile("" ::: "memory");
+            load_a(as, a_offx[1]);
+            load_b(1);
+            if (!lastg) { dma_b(0); dma_a(as ^ 1, 1); CV_END_LOAD(BP + 2) }                  // stage 3g + 3, window part 2; stage 3g + 2 landed
+            else { CV_END_LOAD(0) }
+            mfmas(ah, al);
+            // ---- tx = 2 ----
+            asm volatile("" ::: "memory");
+            load_a(as, a_offx[2]);
+            load_b(2);
+            if (!lastg) { dma_b(1); CV_END_LOAD(BP) }         // stage 3g + 4; stage 3g + 3 and window g + 1 landed
+            else { CV_END_LOAD(0) }
+            mfmas(ah, al);
+        }
+#undef CV_END_LOAD
+        if (grp == 0) __builtin_amdgcn_s_barrier();           // balance group 1's extra barrier
+        __syncthreads();                                      // nothing in flight; the ring is dead
+    } else
+    if constexpr (WIN == 2 && PP) {
+        // ---- ping-pong x register window (DEFAULT for 128-wide 3x3 layers): 256-row tile, two wave groups half a step apart as in the PP
+        // loop below, but the LOAD phase of a sub-step is only the 8 weight-fragment reads (+ the 24 window reads once per group)
+        // and ~3.4 DMA pieces per wave, so it fits under the other group's 48 MFMAs.  Phase order per group: L_s = reads of stage
+        // s, DMA of stage s+2 (and of window g+1 at tx = 1), counted vmcnt for everything older, lgkmcnt(0), barrier; C_s = MFMAs,
+        // barrier.  RAW: a stage is read one L phase after every wave's wait for it and a barrier both groups passed; WAR: a
+        // slot is refilled in the L phase after the one whose reads of it retired before a barrier both groups passed.
+        static_assert(NT == 512 && SPB == 1 && BN % RP == 0 && CV_BM % RP == 0, "8 waves, whole DMA passes");
+        constexpr int BP = 2 * B_PT, AP = 2 * A_PT;
+        unsigned char* const a_win = smem;
+        unsigned char* const b_ring = smem + 2 * A_BYTES;
+        const int aw = CV_BM + 2 * p.tap_sx;
+        const int ngroups = 3 * ksteps_per_tap;
+        int g_ty = 0, g_k0 = 0, bs_tap = 0, bs_k0 = 0;
+        auto dma_a = [&]() {
+            unsigned char* sa_hi = a_win;
+            unsigned char* sa_lo = sa_hi + A_BYTES;
+            const int a_u = (((g_ty + p.tap_o0) * p.tap_sy + p.tap_o0 * p.tap_sx) * p.in_ld + g_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < A_PT; ++i) {
+                CV_BLDS(ra_hi, sa_hi + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+                CV_BLDS(ra_lo, sa_lo + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+            }
+            if (wv == 0 && st_r < aw - CV_BM) {
+                const int ax = a_v[0] + CV_BM * p.in_ld * 2;
+                CV_BLDS(ra_hi, sa_hi + CV_BM * CV_ROW, ax + a_u);
+                CV_BLDS(ra_lo, sa_lo + CV_BM * CV_ROW, ax + a_u);
+            }
+            if (++g_ty == 3) { g_ty = 0; g_k0 += CV_BK; }
+        };
+        auto dma_b = [&](int slot) {
+            unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
+            unsigned char* sb_lo = sb_hi + B_BYTES;
+            const int b_u = (bs_tap * p.cout_pad * p.cin + bs_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < B_PT; ++i) {
+                CV_BLDS(rb_hi, sb_hi + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+                CV_BLDS(rb_lo, sb_lo + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+            }
+            if (++bs_tap == 9) { bs_tap = 0; bs_k0 += CV_BK; }
+        };
+        int a_offx[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) a_offx[tx] = cv_swz(wm * (MF * 16) + frow + tx * p.tap_sx, lane >> 4);
+        bf16x8_t ah[3][MF], al[3][MF], fbh[NFW], fbl[NFW];
+        auto load_b = [&](int slot) {
+            const unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
+            const unsigned char* sb_lo = sb_hi + B_BYTES;
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+                fbh[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
+                fbl[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_lo + b_off + n * 16 * CV_ROW));
+            }
+        };
+        auto mfmas = [&](const bf16x8_t (&xh)[MF], const bf16x8_t (&xl)[MF]) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xl[m], fbh[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xh[m], fbl[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xh[m], fbh[n], acc[m][n]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+#define CV_END_LOAD(N)                                                                         \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");                    \
+        __builtin_amdgcn_s_barrier();
+        const int grp = __builtin_amdgcn_readfirstlane(wv >> 2);
+        dma_a();
+        dma_b(0);
+        dma_b(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BP) : "memory");                 // window 0 and stage 0 landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier (= half a sub-step) behind group 0
+        for (int g = 0; g < ngroups; ++g) {
+            const bool lastg = g + 1 == ngroups;
+            // ---- tx = 0 ----
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int m = 0; m < MF; ++m) {
+                    ah[tx][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + a_offx[tx] + m * 16 * CV_ROW));
+                    al[tx][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + A_BYTES + a_offx[tx] + m * 16 * CV_ROW));
+                }
+            load_b(0);
+            dma_b(2);                                         // stage 3g + 2
+            CV_END_LOAD(BP)                                   // stage 3g + 1 landed
+            mfmas(ah[0], al[0]);
+            // ---- tx = 1 ----
+            asm volatile("" ::: "memory");
+            load_b(1);
+            if (!lastg) {
+                dma_b(0); dma_a();                            // stage 3g + 3, window g + 1
+                if (wv == 0) { CV_END_LOAD(BP + AP + 2) } else { CV_END_LOAD(BP + AP) }      // stage 3g + 2 landed
+            } else { CV_END_LOAD(0) }
+            mfmas(ah[1], al[1]);
+            // ---- tx = 2 ----
+            asm volatile("" ::: "memory");
+            load_b(2);
+            if (!lastg) { dma_b(1); CV_END_LOAD(BP) }         // stage 3g + 4; stage 3g + 3 and window g + 1 landed
+            else { CV_END_LOAD(0) }
+            mfmas(ah[2], al[2]);
+        }
+#undef CV_END_LOAD
+        if (grp == 0) __builtin_amdgcn_s_barrier();           // balance group 1's extra barrier
+        __syncthreads();                                      // nothing in flight; the ring is dead
+    } else
     if constexpr (WIN == 2) {
         // ---- row-window loop, prefetch distance 2 (3x3 layers): the window's fragments for all three tx live in REGISTERS
         // (read once per group), so one LDS window slot suffices and the weight tiles get a 3-slot ring: stage s+2's LDS-DMA is
@@ -653,13 +1015,14 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
                 *reinterpret_cast<uint2*>(act_lo + off) = make_uint2(l01, l23);
             }
         __syncthreads();
-        if constexpr (NT == 256 && CV_BM == 128) {
+        if constexpr ((NT == 256 && CV_BM == 128) || (NT == 512 && CV_BM == 256)) {
             if (!(p.variant & 32)) {                          // dev (MAGNET_CONV_VARIANT=32): the row-owned tail below
-                tail_layer_cols<8, false, CV_BM>(p.tail_w_hi, p.tail_w_lo, p.tail_bias, act_hi, act_lo, nullptr, 0, row0, p.rows, lane, wv);
-                tail_layer_cols<8, false, CV_BM>(p.tail_w_hi + 128 * 128, p.tail_w_lo + 128 * 128, p.tail_bias + 128, act_hi, act_lo, nullptr, 0,
-                                                 row0, p.rows, lane, wv);
-                tail_layer_cols<TAIL, true, CV_BM>(p.tail_w_hi + 2 * 128 * 128, p.tail_w_lo + 2 * 128 * 128, p.tail_bias + 256, act_hi, act_lo,
-                                                   p.out_f32, p.tail_cout, row0, p.rows, lane, wv);
+                constexpr int NW = NT / 64;
+                tail_layer_cols<8, false, CV_BM, NW>(p.tail_w_hi, p.tail_w_lo, p.tail_bias, act_hi, act_lo, nullptr, 0, row0, p.rows, lane, wv);
+                tail_layer_cols<8, false, CV_BM, NW>(p.tail_w_hi + 128 * 128, p.tail_w_lo + 128 * 128, p.tail_bias + 128, act_hi, act_lo, nullptr,
+                                                     0, row0, p.rows, lane, wv);
+                tail_layer_cols<TAIL, true, CV_BM, NW>(p.tail_w_hi + 2 * 128 * 128, p.tail_w_lo + 2 * 128 * 128, p.tail_bias + 256, act_hi, act_lo,
+                                                       p.out_f32, p.tail_cout, row0, p.rows, lane, wv);
                 return;
             }
         }
@@ -759,7 +1122,9 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
 
 template <int NF, int WN, int BM, int SPB, int NT = 256, bool PP = false, int WIN = 0>
 static size_t conv_lds_bytes() {
-    const size_t tiles = WIN == 2 ? 2 * (size_t)(BM + 8) * CV_ROW + 3 * 2 * (size_t)(NF * 16) * CV_ROW
+    const size_t tiles = (WIN == 3 && PP) ? 4 * (size_t)(BM + 8) * CV_ROW + 4 * 2 * (size_t)(NF * 16) * CV_ROW
+                       : (WIN == 1 && PP) ? 4 * (size_t)(BM + 8) * CV_ROW + 3 * 2 * (size_t)(NF * 16) * CV_ROW
+                       : WIN == 2 ? 2 * (size_t)(BM + 8) * CV_ROW + 3 * 2 * (size_t)(NF * 16) * CV_ROW
                                   : (PP ? 3 : 2 * SPB) * (2 * (size_t)(WIN ? BM + 8 : BM) * CV_ROW + 2 * (size_t)(NF * 16) * CV_ROW);
     const size_t stage = (size_t)(NT / 64) * 16 * ((NF / WN) * 16 + 4) * 4;
     return tiles > stage ? tiles : stage;
@@ -800,6 +1165,22 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
             if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, false, 1>(p, s);
             if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, false, 1>(p, s);
         }
+        if (win && p.tap_n == 3 && (p.variant & 128) && (p.cin / 32) % 2 == 0) {   // dev (MAGNET_CONV_VARIANT=128): + fragment double-buffering
+            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 3>(p, s);
+            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 3>(p, s);
+            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true, 3>(p, s);
+        }
+        if (win && p.tap_n == 3 && (p.variant & 64)) {          // dev (MAGNET_CONV_VARIANT=64): ping-pong x 2-slot LDS window, 256-row tile
+            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 1>(p, s);
+            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 1>(p, s);
+            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true, 1>(p, s);
+        }
+        if (win && p.tap_n == 3 && !(p.variant & (16 | 8))) {   // default: ping-pong x register window, 256-row tile, 8 waves
+                                                                // dev (MAGNET_CONV_VARIANT=16): the 4-wave register-window loop below
+            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 2>(p, s);
+            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 2>(p, s);
+            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true, 2>(p, s);
+        }
         if (win && p.tap_n == 3 && !(p.variant & 8)) {          // dev (MAGNET_CONV_VARIANT=8): the 2-slot window loop below
             if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 128, 1, 1, 256, false, 2>(p, s);
             if (p.tail_cout == 128) return launch_conv_nf<8, 2, 128, 1, 8, 256, false, 2>(p, s);
@@ -815,6 +1196,8 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
         if (p.tail_cout == 144) return launch_conv_nf<8, 2, 128, 1, 9>(p, s);
         return hipErrorInvalidValue;
     }
+    // (the 8-wave ping-pong form of this loop, the default of the fused-tail kernels above, is no faster on the F-Net's plain
+    // 128-wide layers: 18.93 vs 18.79 ms per 40 images)
     if (p.cout_pad % 128 == 0 && p.tap_n == 3 && !(p.variant & 9) && !pp) return launch_conv_nf<8, 2, 128, 1, 0, 256, false, 2>(p, s);
     if (p.cout_pad % 128 == 0 && p.tap_n > 1 && !(p.variant & 1) && !pp) return launch_conv_nf<8, 2, 128, 1, 0, 256, false, 1>(p, s);
     if (p.cout_pad % 128 == 0 && pp) return launch_conv_nf<8, 2, 256, 1, 0, 512, true>(p, s);
