@@ -1175,7 +1175,9 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
             if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 1>(p, s);
             if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true, 1>(p, s);
         }
-        if (win && p.tap_n == 3 && !(p.variant & (16 | 8))) {   // default: ping-pong x register window, 256-row tile, 8 waves
+        // default: ping-pong x register window, 256-row tile, 8 waves — when there is at least one such tile per CU (256 CUs);
+        // fewer rows (single-frame inference: 78 tiles at 120x160) spread better as 128-row tiles of the 4-wave kernel
+        if (win && p.tap_n == 3 && !(p.variant & (16 | 8)) && p.rows >= 256ll * 256) {
                                                                 // dev (MAGNET_CONV_VARIANT=16): the 4-wave register-window loop below
             if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 2>(p, s);
             if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 2>(p, s);
