@@ -53,6 +53,20 @@ def test_conv_stack_matches_fp32(hip_lib, gpu, cin, cout, h, w, B, fuse_tail):
     assert torch.isfinite(got).all() and err <= 2e-5 * max(1.0, scale)
 
 
+@pytest.mark.parametrize("cin,cout", [(320, 2), (256, 144)])
+def test_conv_stack_chip_filling_shape_matches_fp32(hip_lib, gpu, cin, cout):
+    """>= one 256-row tile per CU (4 frames of 120x160: 79 056 rows): the launcher picks the 8-wave ping-pong / register-window
+    kernel with the column-owned fused tail (smaller shapes above run the 4-wave kernel); ragged last tile included."""
+    seq = _stack(cin, cout, seed=cin + cout + 1)
+    x = torch.randn(4, cin, 120, 160, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        ref = seq(x)
+    got = _run_stack(seq, x, gpu, fuse_tail="epilogue")
+    err = (got - ref).abs().max().item(); scale = ref.abs().max().item()
+    print(f"[conv {cin}->{cout} 4x120x160] max|d|={err:.3e} max|ref|={scale:.3f} rel={err / scale:.2e}")
+    assert torch.isfinite(got).all() and err <= 2e-5 * max(1.0, scale)
+
+
 def test_conv_stack_channel_map_odd_D(hip_lib, gpu):
     """G-Net with D = 5: cost channels [0,5), x_d3 at channel offset 8 of the 288-wide buffer."""
     seq = _stack(256 + 5, 2, seed=3)
