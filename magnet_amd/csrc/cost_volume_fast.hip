@@ -65,8 +65,14 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
     // ---- wave-private LDS ----
     constexpr int OUT_PX = 8;                             // pixels staged before a coalesced flush (32-byte row segments)
     const int out_bytes = p.cost_hi ? 0 : OUT_PX * DL * 4;
-    const int wave_bytes = p.V * 512 + 16 + 1024 + 272 + out_bytes + (LEAD ? 2048 + 32 : 0);
+    const uint32_t texel_bytes = (uint32_t)p.F * (uint32_t)sizeof(FeatT);
+    // PPW > 1 (D <= 32: several pixels per wave iteration): the reference vectors of the wave's 16 pixels live in LDS.  Read
+    // from global memory per correlation pass they were half of this path's L1 traffic, and the path is L1-bandwidth-bound
+    // (D = 5, fp32 features: 15 TB/s through the 64 B/clk/CU vector-memory path)
+    const int ref_lds = PPW > 1 ? 16 * (int)texel_bytes : 0;
+    const int wave_bytes = p.V * 512 + 16 + 1024 + 272 + out_bytes + (LEAD ? 2048 + 32 : 0) + ref_lds;
     unsigned char* wbase = smem + wv * wave_bytes;
+    unsigned char* refl = wbase + (wave_bytes - ref_lds);                             // [16 px][texel_bytes]
     float4*   pvtab = reinterpret_cast<float4*>(wbase);                               // [V][16 px][2]
     float4*   ctab  = reinterpret_cast<float4*>(wbase + p.V * 512);                   // [zero slot for closed lanes | 64 items] x 4 taps
     uint32_t* items = reinterpret_cast<uint32_t*>(wbase + p.V * 512 + 16 + 1024);     // [64 + pad]
@@ -86,7 +92,6 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
     if (lane == 0) ctab[0] = make_float4(0.f, 0.f, 0.f, 0.f);
     fwave_lds_fence();
 
-    const uint32_t texel_bytes = (uint32_t)p.F * (uint32_t)sizeof(FeatT);
     const int nchunk = (int)(texel_bytes / 16);
     // window 0 <= ixs < w + 1 (padded-map coordinates) as an unsigned compare of the float bits: negative values have the
     // sign bit set, NaNs are above every finite pattern
@@ -100,6 +105,14 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
     const uint32_t lane_src_off = (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes + (uint32_t)sub * 16u;
     const unsigned char* __restrict__ ref_row = reinterpret_cast<const unsigned char*>(p.ref_feat) +
         ((size_t)b * hw + (size_t)yc * p.w) * texel_bytes;                        // reference features of this pixel row
+    if (PPW > 1) {
+        for (int e = lane; e < 16 * nchunk; e += 64) {        // 16 consecutive pixels of the row are contiguous (channel-last)
+            const int q = e / nchunk, c = e - q * nchunk;
+            const int xr = min(x_base + q, p.w - 1);
+            *reinterpret_cast<uint4*>(refl + e * 16) = *reinterpret_cast<const uint4*>(ref_row + (__umul24((uint32_t)xr, texel_bytes) + (uint32_t)c * 16u));
+        }
+        fwave_lds_fence();
+    }
     const float invV = 1.0f / (float)p.V;
     // view validity (homography.py:97) as a bitmask read ONCE
     unsigned long long vmask = 0ull;
@@ -236,8 +249,7 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                             const int it = min(IPP * (ps + a) + upair, nitems);   // tail of the last pass: the pad item
                             const uint32_t item = items[it];
                             const unsigned char* sp = src + (__umul24(item & 0xffffffu, texel_bytes) + lane_src_off);
-                            const int xr = min(x_base + (int)(item >> 26), p.w - 1);
-                            const unsigned char* rp = ref_row + (__umul24((uint32_t)xr, texel_bytes) + (uint32_t)sub * 16u);
+                            const unsigned char* rp = refl + (__umul24(item >> 26, texel_bytes) + (uint32_t)sub * 16u);   // LDS (PPW > 1 only)
 #pragma unroll
                             for (int cc = 0; cc < CPL; ++cc) {
                                 const bool okc = FULL || (sub + LPU * cc < nchunk);
@@ -302,7 +314,9 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
 }
 
 template <int DL>
-static size_t fast_lds_bytes(const CvParams& p) { return (size_t)4 * (p.V * 512 + 16 + 1024 + 272 + (p.cost_hi ? 0 : 8 * DL * 4)); }
+static size_t fast_lds_bytes(const CvParams& p) {
+    return (size_t)4 * (p.V * 512 + 16 + 1024 + 272 + (p.cost_hi ? 0 : 8 * DL * 4) + (DL < 64 ? 16 * p.F * (p.feat_bf16 ? 2 : 4) : 0));
+}
 
 template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU, int MF, int KS>
 static hipError_t launch_fast(const CvParams& p, hipStream_t stream) {
