@@ -21,7 +21,7 @@ hi = torch.zeros(B * (wl.h + 2) * (wl.w + 2), ld, dtype=torch.bfloat16, device=d
 fdt = wl.feat_dtype
 def _dev(vg, lnpx): return 4 | 0x4000 | ((vg - 1) << 9) | (lnpx << 11)
 VARIANTS = [("production (auto)", 0), ("batched VG=1 NPX=8", _dev(1, 3)), ("batched VG=2 NPX=8", _dev(2, 3)), ("batched VG=4 NPX=8", _dev(4, 3)),
-            ("batched VG=4 NPX=16", _dev(4, 4)), ("per-view kernel (16x4 tiles)", 0x8004), ("exact cand", 2)]
+            ("batched VG=4 NPX=16", _dev(4, 4)), ("per-view kernel (16x4 tiles)", 0x8004), ("exact cand", 2), ("production (auto), again", 0)]
 for name, path in VARIANTS:
     if split and (path & 0xff) == 3:
         continue
