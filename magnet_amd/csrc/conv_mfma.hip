@@ -332,6 +332,22 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
     for (int m = 0; m < MF; ++m)
 #pragma unroll
         for (int n = 0; n < NFW; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // fused-tail kernels (C^T accumulators: 4 consecutive channels of one row per lane): the loop-invariant partial sums of the
+    // hoisted G-Net layer (ConvParams::addend) are the accumulators' INITIAL value — sixteen 16-byte loads whose latency hides
+    // behind the K loop's prologue instead of sitting exposed in the epilogue (the short K = 288 / 576 per-iteration layers)
+    if constexpr (TAIL > 0) {
+        if (p.addend) {
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int n = 0; n < NFW; ++n) {
+                    const long long row = row0 + wm * (MF * 16) + m * 16 + (lane & 15);
+                    const int ch = wn * (NFW * 16) + n * 16 + (lane >> 4) * 4;
+                    const float4 a4 = *reinterpret_cast<const float4*>(p.addend + (size_t)(row < p.rows ? row : p.rows - 1) * p.addend_ld + ch);
+                    acc[m][n] = f32x4_t{a4.x, a4.y, a4.z, a4.w};
+                }
+        }
+    }
 
     // fragment addressing: lane -> (row/col = lane & 15, K slot = lane >> 4); every fragment's first row is a
     // multiple of 16, so the swizzle term depends on the lane only
@@ -996,12 +1012,7 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
             for (int n = 0; n < NFW; ++n) {                   // C^T accumulators (cv_mma<true>): 4 consecutive channels of one row
                 const int trow = wm * (MF * 16) + m * 16 + (lane & 15);
                 const int ch = wn * (NFW * 16) + n * 16 + (lane >> 4) * 4;
-                float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
-                if (p.addend) {                               // (acc + addend) + bias: the order of the plain epilogue
-                    const long long row = row0 + trow;
-                    const float4 a4 = *reinterpret_cast<const float4*>(p.addend + (size_t)(row < p.rows ? row : p.rows - 1) * p.addend_ld + ch);
-                    v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
-                }
+                float v[4] = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};   // includes ConvParams::addend (initial value)
                 const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch);
                 v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
                 if (p.relu) {
