@@ -350,7 +350,7 @@ hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled) 
     const size_t esz = p.feat_bf16 ? 2 : 4;
     if ((size_t)(p.h + 2) * (p.w + 2) >= ((size_t)1 << 24)) return hipSuccess;               // 24-bit texel index
     if ((size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets
-    if (fast_lds_bytes<64>(p) > 64 * 1024) return hipSuccess;                                 // absurd V
+    if (fast_lds_bytes<64>(p) > 64 * 1024 || (p.D <= 32 && fast_lds_bytes<32>(p) > 64 * 1024)) return hipSuccess;   // absurd V (D <= 32: + the reference vectors)
     if (p.ablate == 0 || (p.ablate & 0x40)) {                                                 // (bit 15 with bit 14: fast64 dev variant)                                                 // D > 32: views batched per pixel (cost_volume_fast64.hip)
         const hipError_t e = launch_cv_fast64(p, stream, handled);
         if (e != hipSuccess || *handled) return e;
