@@ -130,6 +130,23 @@ def test_fast_shape_sweep(hip_lib, gpu, V, D, F, fdt):
     _check(inp, oracle.depth_sampling(3, D), gpu, fdt=fdt, label=f"sweep V={V} D={D} F={F} {fdt}")
 
 
+def test_many_views_small_D_lds_budget(hip_lib, gpu):
+    """D <= 32 stages the wave's reference vectors in LDS next to the per-view tables: with V = 22, fp32 F = 64 that is more
+    than 64 KB per workgroup.  `path = 4` (production or error) must say so, `path = 0` must fall back to an exact kernel and
+    still give the oracle's volume; V = 12 fits and runs the production kernel."""
+    from magnet_amd import lib
+    wl = synth.Workload("views", "7scenes", 10, 23, V=22, D=5, F=64)
+    inp = synth.make_inputs(wl, B=1, seed=77, invalid=[(0, 3)])
+    k = oracle.depth_sampling(3, wl.D)
+    with pytest.raises(lib.MagnetError):
+        _run(inp, k, gpu, path=4, want_gates=False)
+    cost, _ = _run(inp, k, gpu, path=0, want_gates=False)
+    orc = oracle_cost(inp, k)
+    np.testing.assert_allclose(cost.cpu().numpy(), orc, rtol=2e-5, atol=2e-5)
+    wl12 = synth.Workload("views12", "7scenes", 10, 23, V=12, D=5, F=64)
+    _check(synth.make_inputs(wl12, B=1, seed=78), k, gpu, label="V=12 D=5")
+
+
 def test_fast_nan_and_degenerate_inputs(hip_lib, gpu):
     """NaN / zero sigma / zero depth in the reference gmm and a singular pose (test_gpu_parity.py's case)."""
     wl = synth.Workload("nan", "scannet", 12, 16, V=2, D=8, F=8)
