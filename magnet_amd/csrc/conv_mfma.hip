@@ -742,11 +742,13 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
         // (loads retire in order: "all but the pieces issued in the previous sub-step" = stage s landed).  Issuing the pieces
         // later in the sub-step, between the MFMAs, was measured 2.5 % slower, s_setprio around the MFMA block 1 % slower (same box A/B).  3 sub-steps per
         // group and 3 slots: stage s = 3g + tx lives in slot tx — every LDS address below is static.
-        static_assert(!PP && SPB == 1 && NT == 256 && BN % RP == 0, "window loop with register-resident A: 4 waves, whole DMA passes");
+        static_assert(!PP && SPB == 1 && NT == 256 && (BN % RP == 0 || BN == 32), "window loop with register-resident A: 4 waves, whole DMA passes (or the 32-wide case)");
         // Measured and rejected: the same loop with a 2-slot weight ring and a two-pass (2 x 64 rows) fused tail so that THREE
         // workgroups fit a CU (49 KB of LDS, <= 168 registers): 96 of the 168 registers hold the window, the compiler serialises the
         // weight fragment reads with the MFMAs: 9.4 vs 5.0 ms of convolutions per C2 step.
-        constexpr int BP = 2 * B_PT;                          // weight-tile DMA instructions per wave and stage
+        // BN = 32 (F-Net's 32-wide trunk): the weight tile is 4 pieces of 16 rows — wave w stages plane w & 1, rows (w >> 1) * 16 ...,
+        // ONE piece per wave, so the counted waits stay wave-uniform (row-pass staging would give waves 2 and 3 nothing to count)
+        constexpr int BP = BN == 32 ? 1 : 2 * B_PT;           // weight-tile DMA instructions per wave and stage
         constexpr int AP = 2 * A_PT;                          // window DMA instructions per wave (wave 0: + 2 for the rows past the tile)
         unsigned char* const a_win = smem;                    // [hi | lo], AW_ROWS rows each
         unsigned char* const b_ring = smem + 2 * A_BYTES;     // 3 x [hi | lo]
@@ -769,14 +771,20 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
             }
             if (++g_ty == 3) { g_ty = 0; g_k0 += CV_BK; }
         };
+        const int b_v32 = ((n0 + (wv >> 1) * 16 + (lane >> 2)) * p.cin + st_k) * 2;       // BN = 32: this wave's 16 weight rows
         auto dma_b = [&](int slot) {
             unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
             unsigned char* sb_lo = sb_hi + B_BYTES;
             const int b_u = (bs_tap * p.cout_pad * p.cin + bs_k0) * 2;
+            if constexpr (BN == 32) {
+                if (wv & 1) CV_BLDS(rb_lo, sb_lo + (wv >> 1) * 16 * CV_ROW, b_v32 + b_u);
+                else        CV_BLDS(rb_hi, sb_hi + (wv >> 1) * 16 * CV_ROW, b_v32 + b_u);
+            } else {
 #pragma unroll
-            for (int i = 0; i < B_PT; ++i) {
-                CV_BLDS(rb_hi, sb_hi + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
-                CV_BLDS(rb_lo, sb_lo + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+                for (int i = 0; i < B_PT; ++i) {
+                    CV_BLDS(rb_hi, sb_hi + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+                    CV_BLDS(rb_lo, sb_lo + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+                }
             }
             if (++bs_tap == 9) { bs_tap = 0; bs_k0 += CV_BK; }
         };
@@ -1219,9 +1227,10 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
     if (p.cout_pad == 16)  return launch_conv_nf<1, 1, 128, 1>(p, s);
     // F-Net trunk widths: 4 waves stacked along M.  Measured on the whole F-Net (40 images, 23.5 ms): 256-row tiles for
     // the 32- / 64-wide layers 24.1 / 24.2 ms, 192-row tile for 64-wide 24.6 ms, 2x2 waves for 64-wide 23.6 ms — no better.
-    // 64-wide 3x3 layers of the trunk: the register-window loop too (their A operand is 2/3 of the DMA pieces of a K step;
-    // the 32-wide ones would need per-wave vmcnt counts: only two of the four waves stage weight rows); dev
+    // 32- and 64-wide 3x3 layers of the trunk: the register-window loop too (their A operand is 2/3 of the DMA pieces of a K
+    // step); dev
     // (MAGNET_CONV_VARIANT=8): one A stage per tap
+    if (p.cout_pad == 32 && p.tap_n == 3 && !(p.variant & 9))  return launch_conv_nf<2, 1, 128, 1, 0, 256, false, 2>(p, s);
     if (p.cout_pad == 64 && p.tap_n == 3 && !(p.variant & 9))  return launch_conv_nf<4, 1, 128, 1, 0, 256, false, 2>(p, s);
     if (p.cout_pad == 32)  return launch_conv_nf<2, 1, 128, 1>(p, s);
     if (p.cout_pad == 64)  return launch_conv_nf<4, 1, 128, 1>(p, s);
