@@ -38,7 +38,7 @@ extern "C" {
 
 #define MAGNET_API __attribute__((visibility("default")))
 
-#define MAGNET_HIP_VERSION 200            /* major*10000 + minor*100 + patch */
+#define MAGNET_HIP_VERSION 201            /* major*10000 + minor*100 + patch */
 
 enum {                                     /* storage dtype of channel-last feature maps */
     MAGNET_FEAT_F32  = 0,
@@ -274,6 +274,10 @@ MAGNET_API int magnet_gaussian_update_cl(const float *gnet_out_pad, int32_t ld, 
  * (B, h+2, w+2, ld), channel n*k*k + i*k + j as in models/MAGNET.py:19; depth (B,2,h,w) -> out (B,2,4h,4w); k = 4. */
 MAGNET_API int magnet_upsample_depth_cl(const float *depth, const float *mask_pad, int32_t ld, float *out,
                                         int32_t B, int32_t h, int32_t w, void *stream);
+/* The same for n_pred stacked predictions in one launch: depths (n_pred,B,2,h,w), outs (n_pred,B,2,4h,4w); the mask is read and
+ * soft-maxed once (models/MAGNET.py:173 upsamples every iteration's prediction with the same mask). */
+MAGNET_API int magnet_upsample_depth_cl_n(const float *depths, const float *mask_pad, int32_t ld, float *outs, int32_t n_pred,
+                                          int32_t B, int32_t h, int32_t w, void *stream);
 
 /* Depth-error reductions on the device (utils.compute_depth_errors, utils/utils.py:106-144, with the masking /
  * clamping of test_MaGNet.py:43,58-79): pred (B,2,H*W) [mu, sigma], gt (B,H*W).  sums: OUT double (B,16), zeroed by

@@ -15,7 +15,7 @@ hipError_t launch_gaussian_update(const float*, const float*, float*, int, int, 
 hipError_t launch_upsample(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 hipError_t launch_pack_split(const float*, uint16_t*, uint16_t*, int, int, int, int, int, int, long long, hipStream_t);
 hipError_t launch_gaussian_update_cl(const float*, int, const float*, float*, int, int, int, hipStream_t);
-hipError_t launch_upsample_cl(const float*, const float*, int, float*, int, int, int, hipStream_t);
+hipError_t launch_upsample_cl(const float*, const float*, int, float*, int, int, int, int, hipStream_t);
 hipError_t launch_fnet_stem(const float*, const float*, const float*, uint16_t*, uint16_t*, int, int, int, hipStream_t);
 hipError_t launch_space_to_depth(const uint16_t*, const uint16_t*, uint16_t*, uint16_t*, int, int, int, int, int, hipStream_t);
 hipError_t launch_avgpool_cl(const uint16_t*, const uint16_t*, int, int, int, int, int, int, int, uint16_t*, uint16_t*, hipStream_t);
@@ -403,8 +403,18 @@ MAGNET_API int magnet_upsample_depth_cl(const float* depth, const float* mask_pa
     if (!depth || !mask_pad || !out) return fail(MAGNET_E_NULL, "magnet_upsample_depth_cl: NULL pointer");
     if (B <= 0 || h <= 0 || w <= 0 || ld < 144 || (ld % 4)) return fail(MAGNET_E_DIM, "magnet_upsample_depth_cl: bad dims (ld >= 144, ld %% 4 == 0)");
     if (!aligned16(out) || !aligned16(mask_pad)) return fail(MAGNET_E_ALIGN, "magnet_upsample_depth_cl: pointers not 16-byte aligned");
-    hipError_t e = magnet::launch_upsample_cl(depth, mask_pad, ld, out, B, h, w, (hipStream_t)stream);
+    hipError_t e = magnet::launch_upsample_cl(depth, mask_pad, ld, out, B, h, w, 1, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_upsample_depth_cl launch");
+}
+
+MAGNET_API int magnet_upsample_depth_cl_n(const float* depths, const float* mask_pad, int32_t ld, float* outs, int32_t n_pred, int32_t B,
+                                          int32_t h, int32_t w, void* stream) {
+    if (!depths || !mask_pad || !outs) return fail(MAGNET_E_NULL, "magnet_upsample_depth_cl_n: NULL pointer");
+    if (n_pred <= 0 || n_pred > 64 || B <= 0 || h <= 0 || w <= 0 || ld < 144 || (ld % 4))
+        return fail(MAGNET_E_DIM, "magnet_upsample_depth_cl_n: bad dims (1 <= n_pred <= 64, ld >= 144, ld %% 4 == 0)");
+    if (!aligned16(outs) || !aligned16(mask_pad)) return fail(MAGNET_E_ALIGN, "magnet_upsample_depth_cl_n: pointers not 16-byte aligned");
+    hipError_t e = magnet::launch_upsample_cl(depths, mask_pad, ld, outs, B, h, w, n_pred, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_upsample_depth_cl_n launch");
 }
 
 MAGNET_API int magnet_depth_metrics(const float* pred, const float* gt, double* sums, int32_t B, int32_t HW, float min_depth,

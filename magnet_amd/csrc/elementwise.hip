@@ -206,8 +206,10 @@ hipError_t launch_gaussian_update_cl(const float* o, int ld, const float* g, flo
 
 // convex x4 upsampling with the mask in padded channel-last fp32 (B, h+2, w+2, ld): thread = (pixel, sub-row i);
 // the 4 sub-columns j of one neighbour n are 16 contiguous bytes (channel n*16 + i*4 + j, MAGNET.py:19)
+// n_pred stacked (mu, sigma) maps (n_pred, B, 2, h, w) share one read of the mask and one softmax: the refinement loop returns
+// every iteration's prediction upsampled (MAGNET.py:173), and the mask (B, 144, h, w as fp32) is 4.6x the bytes of one output
 __global__ __launch_bounds__(256) void upsample_cl_kernel(const float* __restrict__ depth, const float* __restrict__ mask,
-                                                           int ld, float* __restrict__ out, int B, int h, int w) {
+                                                           int ld, float* __restrict__ out, int B, int h, int w, int n_pred) {
     const size_t hw = (size_t)h * w;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (size_t)B * hw * 4) return;
@@ -231,22 +233,27 @@ __global__ __launch_bounds__(256) void upsample_cl_kernel(const float* __restric
     }
     const float4 inv = make_float4(1.0f / den.x, 1.0f / den.y, 1.0f / den.z, 1.0f / den.w);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = 0; n < 9; ++n) { mv[n].x *= inv.x; mv[n].y *= inv.y; mv[n].z *= inv.z; mv[n].w *= inv.w; }
+    for (int pi = 0; pi < n_pred; ++pi) {
 #pragma unroll
-        for (int n = 0; n < 9; ++n) {
-            const int yy = y + n / 3 - 1, xx = x + n % 3 - 1;
-            const float dv = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? depth[((size_t)b * 2 + c) * hw + (size_t)yy * w + xx] : 0.f;
-            a.x += (mv[n].x * inv.x) * dv; a.y += (mv[n].y * inv.y) * dv;
-            a.z += (mv[n].z * inv.z) * dv; a.w += (mv[n].w * inv.w) * dv;
+        for (int c = 0; c < 2; ++c) {
+            const size_t plane = ((size_t)pi * B + b) * 2 + c;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < 9; ++n) {
+                const int yy = y + n / 3 - 1, xx = x + n % 3 - 1;
+                const float dv = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? depth[plane * hw + (size_t)yy * w + xx] : 0.f;
+                a.x += mv[n].x * dv; a.y += mv[n].y * dv;
+                a.z += mv[n].z * dv; a.w += mv[n].w * dv;
+            }
+            *reinterpret_cast<float4*>(out + (plane * h * 4 + (size_t)y * 4 + i) * ((size_t)w * 4) + (size_t)x * 4) = a;
         }
-        *reinterpret_cast<float4*>(out + (((size_t)b * 2 + c) * h * 4 + (size_t)y * 4 + i) * ((size_t)w * 4) + (size_t)x * 4) = a;
     }
 }
 
-hipError_t launch_upsample_cl(const float* d, const float* m, int ld, float* o, int B, int h, int w, hipStream_t s) {
+hipError_t launch_upsample_cl(const float* d, const float* m, int ld, float* o, int B, int h, int w, int n_pred, hipStream_t s) {
     const size_t n = (size_t)B * h * w * 4;
-    hipLaunchKernelGGL(upsample_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, m, ld, o, B, h, w);
+    hipLaunchKernelGGL(upsample_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, m, ld, o, B, h, w, n_pred);
     return hipGetLastError();
 }
 

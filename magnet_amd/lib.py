@@ -355,7 +355,7 @@ class MagnetConvArgs(ctypes.Structure):
 
 
 API_SYMBOLS = API_SYMBOLS + ("magnet_conv_mfma", "magnet_pack_split", "magnet_gaussian_update_cl",
-                             "magnet_upsample_depth_cl")
+                             "magnet_upsample_depth_cl", "magnet_upsample_depth_cl_n")
 
 
 def _conv_protos(lib):
@@ -370,6 +370,8 @@ def _conv_protos(lib):
     lib.magnet_gaussian_update_cl.argtypes = [P, I, P, P, I, I, I, P]
     lib.magnet_upsample_depth_cl.restype = ctypes.c_int
     lib.magnet_upsample_depth_cl.argtypes = [P, P, I, P, I, I, I, P]
+    lib.magnet_upsample_depth_cl_n.restype = ctypes.c_int
+    lib.magnet_upsample_depth_cl_n.argtypes = [P, P, I, P, I, I, I, I, P]
     lib._conv_protos_done = True
     return lib
 
@@ -457,6 +459,23 @@ def upsample_depth_cl(depth, mask_pad, ld, out=None):
         _check(lib.magnet_upsample_depth_cl(d.data_ptr(), _dev(mask_pad, "mask_pad", torch.float32).data_ptr(), int(ld),
                                             out.data_ptr(), B, h, w, _stream(d)), "magnet_upsample_depth_cl")
     return out
+
+
+def upsample_depth_cl_n(depths, mask_pad, ld):
+    """Every prediction of the refinement loop upsampled with the same mask in ONE launch (models/MAGNET.py:173): `depths` is a
+    list of (B,2,h,w) tensors; returns the list of (B,2,4h,4w) outputs (contiguous slices of one buffer)."""
+    lib = _conv_protos(load())
+    if len(depths) == 1:
+        return [upsample_depth_cl(depths[0], mask_pad, ld)]
+    d = torch.stack([_dev(x, "depth", torch.float32) for x in depths])
+    n, B, C, h, w = d.shape
+    if C != 2:
+        raise MagnetError("upsample_depth_cl_n: depths must be (B,2,h,w)")
+    out = torch.empty((n, B, 2, 4 * h, 4 * w), dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device):
+        _check(lib.magnet_upsample_depth_cl_n(d.data_ptr(), _dev(mask_pad, "mask_pad", torch.float32).data_ptr(), int(ld),
+                                              out.data_ptr(), n, B, h, w, _stream(d)), "magnet_upsample_depth_cl_n")
+    return [out[i] for i in range(n)]
 
 
 API_SYMBOLS = API_SYMBOLS + ("magnet_conv1x1_chain",)

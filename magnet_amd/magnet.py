@@ -291,7 +291,7 @@ class MAGNET(nn.Module):
         else:
             main.wait_event(ev_mask)
         mask_pad, mask_ld = mask_out
-        return [lib.upsample_depth_cl(pred, mask_pad, mask_ld) for pred in pred_list[1:]]            # MAGNET.py:173
+        return lib.upsample_depth_cl_n(pred_list[1:], mask_pad, mask_ld)                              # MAGNET.py:173 (one launch)
 
     def forward(self, ref_img, nghbr_imgs, nghbr_poses, is_valid, cam_intrins, mode="train"):
         B = ref_img.shape[0]
