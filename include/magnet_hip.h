@@ -13,7 +13,7 @@
  *   magnet_upsample_depth    -> upsample_depth_via_mask       (models/MAGNET.py:15-27)
  *   magnet_depth_metrics     -> utils.compute_depth_errors + validate()'s masking (utils/utils.py:106-144,
  *                               test_MaGNet.py:43,58-79), so full depth maps never leave the device
- *   magnet_conv_mfma (+ magnet_pack_split, magnet_gaussian_update_cl, magnet_upsample_depth_cl)
+ *   magnet_conv_mfma (+ magnet_pack_split, magnet_gaussian_update_cl, magnet_upsample_depth_cl[_n])
  *                            -> the g_net / mask_head nn.Conv2d stacks (models/MAGNET.py:51-56,111-116)
  *
  * Conventions
