@@ -38,7 +38,7 @@ extern "C" {
 
 #define MAGNET_API __attribute__((visibility("default")))
 
-#define MAGNET_HIP_VERSION 201            /* major*10000 + minor*100 + patch */
+#define MAGNET_HIP_VERSION 300            /* major*10000 + minor*100 + patch */
 
 enum {                                     /* storage dtype of channel-last feature maps */
     MAGNET_FEAT_F32  = 0,
@@ -50,7 +50,9 @@ enum {                                     /* argument errors (positive return v
     MAGNET_E_DIM      = 2,                 /* a dimension is <= 0 or exceeds a kernel limit */
     MAGNET_E_DTYPE    = 3,                 /* unknown dtype enum */
     MAGNET_E_ALIGN    = 4,                 /* a pointer is not 16-byte aligned */
-    MAGNET_E_NODEVICE = 5                  /* no gfx950 device / kernel image not loadable */
+    MAGNET_E_NODEVICE = 5,                 /* no gfx950 device / kernel image not loadable */
+    MAGNET_E_SHAPE    = 6                  /* valid arguments, but the kernel selected by `path` (or the requested output form)
+                                              does not take this shape / option set: choose another path.  Never a HIP failure. */
 };
 
 #define MAGNET_MAX_CANDIDATES 256          /* D limit of magnet_cost_volume_cw */
@@ -76,18 +78,24 @@ typedef struct MagnetCostVolumeArgs {
     const float   *intM;                   /* (B,3,3) intrinsics at grid resolution */
     const float   *rays;                   /* (B,3,h*w) unit_ray_array_2D; may be NULL when ray_params is given (path 0/1/2/4) */
     float         *cost;                   /* OUT (B,D,h,w) fp32; frame b starts at cost + b*cost_batch_stride */
-    int32_t        path;                   /* kernel selection, low 8 bits:
-                                              0 = auto: the PRODUCTION matcher (tolerance parity: gate-flip fraction <= 1e-5,
-                                                  values within 2e-5 + 2e-5|c| of the reference elsewhere) whenever the candidates
-                                                  are sampled in the kernel (d_volume == NULL, mode 0, stats == NULL); otherwise
-                                                  the exact candidate-lane kernel; the generic kernel for shapes neither takes;
+    int32_t        path;                   /* kernel selection:
+                                              0 = auto: the PRODUCTION matcher whenever the candidates are sampled in the kernel
+                                                  (d_volume == NULL, mode 0, stats == NULL); otherwise the exact candidate-lane
+                                                  kernel; the generic kernel for shapes neither takes.
+                                                  Production contract (TOLERANCE parity with homography.py:124-161): at most a 1e-5
+                                                  fraction of the consistency gates differs from the reference's; every entry none
+                                                  of whose gates differs is within 2e-5 + 2e-5|c| + eps*S of the reference, where
+                                                  S = sum over open views of (|dc/dx| + |dc/dy|) is the score's slope in the sample
+                                                  position and eps = 4 ulp(max(h, w) + 1) texels: the kernel's sample position
+                                                  differs from the reference's by its normalise / unnormalise rounding (<= 1.5e-5
+                                                  texel), so on features that vary strongly from texel to texel (white noise) the
+                                                  plain 2e-5 + 2e-5|c| bound alone does NOT hold; on smooth features it does
+                                                  (tests/test_gpu_fast_matcher.py);
                                               1 = generic gather kernel (bit-exact reference arithmetic, slow);
-                                              2 = exact candidate-lane kernel (the reference's fp32 geometry to the bit) or error;
-                                              3 = exact pixel-lane worklist kernel or error;
-                                              4 = production matcher or error.
-                                              Bits 8..15 are DEVELOPMENT switches (timing ablations used by tools/ablate.py;
-                                              results are not meaningful with any of them set except bit 8 on path 0/4, which
-                                              only moves the channel contraction from the matrix pipe to the vector ALU). */
+                                              2 = exact candidate-lane kernel (the reference's fp32 geometry to the bit) or MAGNET_E_SHAPE;
+                                              3 = exact pixel-lane worklist kernel or MAGNET_E_SHAPE;
+                                              4 = production matcher or MAGNET_E_SHAPE.
+                                              Any other value: MAGNET_E_DIM. */
     uint32_t      *stats;                  /* optional device uint32[4]: {tiles run by a fast kernel, tiles run by the
                                               generic kernel, items (distinct open quads) correlated, 0}, accumulated with atomics; NULL = off */
     int64_t        cost_batch_stride;      /* elements between consecutive frames of `cost`; 0 = D*h*w (dense).
@@ -114,6 +122,13 @@ typedef struct MagnetCostVolumeArgs {
                                               ((x+0.5)*sx - cx + left)/fx in float64 per reference pixel instead of reading the
                                               12*h*w-byte table (dataloader_scannet.py:139-147, dataloader_kitti.py:113-118) —
                                               bit-identical to it.  The worklist kernel and the backward need the table. */
+    const float   *src_gmm_quad;           /* optional (V*B, h+2, w+2, 8): the source (mu, sigma) map per QUAD ORIGIN of the padded map in
+                                              quad form {m00, m10-m00, m01-m00, m11-m10-m01+m00, s00, ...} (magnet_pack_gmm_quad), so that
+                                              a bilinear sample is 3 fma per channel.  The production matcher for D > 32 needs it
+                                              (without it path 0 runs the round-2 production kernel, path 4 too). */
+    uint32_t       dev_flags;              /* development switches (timing ablations, kernel variants of tools/ablate.py).  Ignored
+                                              unless the library was built with -DMAGNET_DEV (python -m magnet_amd.build --dev);
+                                              results are not meaningful with any of them set. */
 } MagnetCostVolumeArgs;
 
 MAGNET_API int magnet_version(void);
@@ -129,6 +144,12 @@ MAGNET_API int magnet_pack_features(const float *nchw, void *out_cl, int32_t N, 
 
 /* (N,2,h,w) fp32 [mu,sigma] planes -> (N,h+2,w+2,2) interleaved with a one-texel zero border. */
 MAGNET_API int magnet_pack_gmm(const float *gmm_nchw, float *out_pad, int32_t N, int32_t h, int32_t w, void *stream);
+
+/* (N,2,h,w) fp32 [mu,sigma] planes -> (N,h+2,w+2,8): entry (y0,x0) describes the 2x2 quad of the zero-bordered map whose top-left
+ * texel is padded position (y0,x0) (texels outside the padded map count as zero), as
+ * {m00, m10-m00, m01-m00, (m11-m01)-(m10-m00), s00, s10-s00, s01-s00, (s11-s01)-(s10-s00)} (x is the fast index of mXY).
+ * Feeds MagnetCostVolumeArgs.src_gmm_quad (grid_sample of the (mu, sigma) maps, homography.py:151-152). */
+MAGNET_API int magnet_pack_gmm_quad(const float *gmm_nchw, float *out_quad, int32_t N, int32_t h, int32_t w, void *stream);
 
 /* Consistency-weighted multi-view matching score, all (b, pixel, candidate) in one launch. */
 MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs *args, void *stream);

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmagnet_hip.so")
-SOURCES = ["api.hip", "cost_volume.hip", "cost_volume_worklist.hip", "cost_volume_cand.hip", "cost_volume_fast.hip", "cost_volume_fast64.hip", "cost_volume_f_bwd.hip", "cost_volume_f_gather.hip", "conv_mfma.hip", "fnet_kernels.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "cost_volume.hip", "cost_volume_worklist.hip", "cost_volume_cand.hip", "cost_volume_fast.hip", "cost_volume_fast64.hip", "cost_volume_v3.hip", "cost_volume_f_bwd.hip", "cost_volume_f_gather.hip", "conv_mfma.hip", "fnet_kernels.hip", "elementwise.hip"]
 HEADERS = ["cv_common.hpp", "cv_fast_common.hpp", "conv_common.hpp", "warp_math.hpp", os.path.join("..", "..", "include", "magnet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fvisibility=hidden",
@@ -39,17 +39,23 @@ def _stale() -> bool:
 # Per-file flags.  The matcher kernels are VALU-issue-bound; clang's SLP vectoriser packs adjacent fp32 mul/add/fma into
 # v_pk_*_f32, which on gfx950 run at HALF the per-instruction rate of their scalar forms (tools/ubench/valu_rate.hip: 4.9 vs
 # 2.5 cycles) and need their operands copied into aligned register pairs (55 v_mov per 4 views): packing is a net loss there.
-EXTRA_FLAGS = {"cost_volume_fast.hip": ["-fno-slp-vectorize"], "cost_volume_fast64.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"cost_volume_fast.hip": ["-fno-slp-vectorize"], "cost_volume_fast64.hip": ["-fno-slp-vectorize"],
+               "cost_volume_v3.hip": ["-fno-slp-vectorize"]}
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, dev: bool | None = None) -> str:
+    """dev=True (or MAGNET_DEV=1 in the environment): compile with -DMAGNET_DEV, which makes the library honour
+    MagnetCostVolumeArgs.dev_flags and the MAGNET_* environment switches of tools/ (kernel variants, timing ablations).
+    The product build ignores all of them."""
+    if dev is None:
+        dev = os.environ.get("MAGNET_DEV", "") not in ("", "0")
+    if not force and not _stale() and not dev:
         return LIB
     objs = []
     procs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc(), *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc(), *FLAGS, *(["-DMAGNET_DEV"] if dev else []), *EXTRA_FLAGS.get(s, []), "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -66,4 +72,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv or "--dev" in sys.argv, verbose=True, dev=True if "--dev" in sys.argv else None))

@@ -11,6 +11,7 @@
 namespace magnet {
 hipError_t launch_pack(const float*, void*, int, int, int, int, bool, int, hipStream_t);
 hipError_t launch_pack_gmm(const float*, float*, int, int, int, hipStream_t);
+hipError_t launch_pack_gmm_quad(const float*, float*, int, int, int, hipStream_t);
 hipError_t launch_gaussian_update(const float*, const float*, float*, int, int, hipStream_t);
 hipError_t launch_upsample(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 hipError_t launch_pack_split(const float*, uint16_t*, uint16_t*, int, int, int, int, int, int, long long, hipStream_t);
@@ -78,19 +79,27 @@ MAGNET_API int magnet_pack_gmm(const float* gmm_nchw, float* out_pad, int32_t N,
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_pack_gmm launch");
 }
 
+MAGNET_API int magnet_pack_gmm_quad(const float* gmm_nchw, float* out_quad, int32_t N, int32_t h, int32_t w, void* stream) {
+    if (!gmm_nchw || !out_quad) return fail(MAGNET_E_NULL, "magnet_pack_gmm_quad: NULL pointer");
+    if (N <= 0 || h <= 0 || w <= 0) return fail(MAGNET_E_DIM, "magnet_pack_gmm_quad: bad dims N=%d h=%d w=%d", N, h, w);
+    if (!aligned16(out_quad)) return fail(MAGNET_E_ALIGN, "magnet_pack_gmm_quad: out_quad not 16-byte aligned");
+    hipError_t e = magnet::launch_pack_gmm_quad(gmm_nchw, out_quad, N, h, w, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_pack_gmm_quad launch");
+}
+
 // argument checks + launch parameters shared by the matcher and the backward of its mode 1
 static int cv_prepare(const MagnetCostVolumeArgs* a, magnet::CvParams& p, bool backward) {
     if (!a) return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: args is NULL");
     if (!a->ref_feat_cl || !a->src_feat_pad || (!a->src_gmm_pad && a->mode != 1) || !a->poses || !a->is_valid || !a->intM ||
         (!a->rays && !a->ray_params) || (!backward && !a->cost && !a->cost_hi))
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: a required pointer is NULL");
-    if (!a->rays && (backward || (a->path & 0xff) == 3))
+    if (!a->rays && (backward || a->path == 3))
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: this kernel reads the ray table (ray_params alone serves path 0/1/2/4 forward): "
                                    "build it with magnet_make_rays");
     if (a->mode != 0 && a->mode != 1) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: unknown mode %d", a->mode);
     if (a->mode == 1 && (!a->k_list || a->d_volume))
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: mode 1 takes its depth bins from k_list (d_volume must be NULL)");
-    if (a->mode == 1 && (a->path & 0xff) == 3)
+    if (a->mode == 1 && a->path == 3)
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: mode 1 is not implemented in the worklist kernel");
     if (a->mode == 0 && !a->d_volume && (!a->ref_gmm || !a->k_list))
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: d_volume is NULL, so ref_gmm and k_list are required");
@@ -101,6 +110,7 @@ static int cv_prepare(const MagnetCostVolumeArgs* a, magnet::CvParams& p, bool b
     if ((a->F % 8) != 0) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: F=%d must be a multiple of 8", a->F);
     if (a->feat_dtype != MAGNET_FEAT_F32 && a->feat_dtype != MAGNET_FEAT_BF16)
         return fail(MAGNET_E_DTYPE, "magnet_cost_volume_cw: unknown feat_dtype %d", a->feat_dtype);
+    if (a->src_gmm_quad && !aligned16(a->src_gmm_quad)) return fail(MAGNET_E_ALIGN, "magnet_cost_volume_cw: src_gmm_quad must be 16-byte aligned");
     if (!aligned16(a->ref_feat_cl) || !aligned16(a->src_feat_pad))
         return fail(MAGNET_E_ALIGN, "magnet_cost_volume_cw: feature pointers must be 16-byte aligned");
     if (a->V > 64) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: V=%d exceeds 64 source views", a->V);
@@ -115,9 +125,13 @@ static int cv_prepare(const MagnetCostVolumeArgs* a, magnet::CvParams& p, bool b
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: grid too large");
     p.feat_bf16 = (a->feat_dtype == MAGNET_FEAT_BF16);
     p.kappa = a->kappa;
-    p.ablate = (a->path >> 8) & 0xff;
+#ifdef MAGNET_DEV
+    p.ablate = (int)(a->dev_flags & 0xffffffu);                    // development switches: never in the product build
+#else
+    p.ablate = 0;
+#endif
     p.mode_f = a->mode;
-    p.ref_feat = a->ref_feat_cl; p.src_feat = a->src_feat_pad; p.src_gmm = a->src_gmm_pad;
+    p.ref_feat = a->ref_feat_cl; p.src_feat = a->src_feat_pad; p.src_gmm = a->src_gmm_pad; p.src_gmq = a->src_gmm_quad;
     p.ref_gmm = a->ref_gmm; p.d_volume = a->d_volume; p.poses = a->poses; p.is_valid = a->is_valid;
     p.intM = a->intM; p.rays = a->rays; p.cost = a->cost; p.stats = a->stats;
     p.cost_hi = (uint16_t*)a->cost_hi; p.cost_lo = (uint16_t*)a->cost_lo; p.cost_ld = a->cost_ld;
@@ -125,10 +139,10 @@ static int cv_prepare(const MagnetCostVolumeArgs* a, magnet::CvParams& p, bool b
     p.ray_params = a->rays ? nullptr : a->ray_params;           // the table wins when both are given
     if (a->cost_hi && (!a->cost_lo || a->cost_ld < a->D))
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: cost_hi needs cost_lo and cost_ld >= D");
-    if (a->cost_hi && (a->path & 0xff) != 0 && (a->path & 0xff) != 2 && (a->path & 0xff) != 4)
-        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the split channel-last output exists only in the candidate-lane kernels (path 0/2/4)");
-    if (a->gate_bits && ((a->path & 0xff) == 1 || (a->path & 0xff) == 3 || a->mode != 0))
-        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: gate_bits is written by the candidate-lane kernels only (path 0/2/4, mode 0)");
+    if (a->cost_hi && a->path != 0 && a->path != 2 && a->path != 4)
+        return fail(MAGNET_E_SHAPE, "magnet_cost_volume_cw: the split channel-last output exists only in the candidate-lane kernels (path 0/2/4)");
+    if (a->gate_bits && (a->path == 1 || a->path == 3 || a->mode != 0))
+        return fail(MAGNET_E_SHAPE, "magnet_cost_volume_cw: gate_bits is written by the candidate-lane kernels only (path 0/2/4, mode 0)");
     p.cost_bstride = a->cost_batch_stride ? a->cost_batch_stride : (long long)a->D * a->h * a->w;
     if (p.cost_bstride < (long long)a->D * a->h * a->w)
         return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: cost_batch_stride smaller than D*h*w");
@@ -142,30 +156,29 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
     if (const int rc = cv_prepare(a, p, false)) return rc;
     hipError_t e = hipSuccess;
     bool handled = false;
-    const int path = a->path & 0xff;
+    const int path = a->path;
+    if (path < 0 || path > 4) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: unknown path %d", path);
     if (path == 0 || path == 4) {
         e = magnet::launch_cv_fast(p, (hipStream_t)stream, &handled);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw production-matcher launch");
         if (!handled && path == 4)
-            return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the production matcher needs fused sampling (d_volume == NULL), mode 0, "
+            return fail(MAGNET_E_SHAPE, "magnet_cost_volume_cw: the production matcher needs fused sampling (d_volume == NULL), mode 0, "
                                       "stats == NULL and F*sizeof(feature) <= 512");
     }
     if (!handled && (path == 0 || path == 2)) {
         e = magnet::launch_cv_cand(p, (hipStream_t)stream, &handled);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw candidate-lane launch");
         if (!handled && path == 2)
-            return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the candidate-lane kernel does not take this shape");
+            return fail(MAGNET_E_SHAPE, "magnet_cost_volume_cw: the candidate-lane kernel does not take this shape");
     } else if (handled) {
     } else if (path == 3) {
         e = magnet::launch_cv_worklist(p, (hipStream_t)stream, &handled);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw worklist launch");
         if (!handled)
-            return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: the worklist kernel does not take this shape (D > 128 or very wide F)");
-    } else if (path != 1 && path != 4) {
-        return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: unknown path %d", path);
+            return fail(MAGNET_E_SHAPE, "magnet_cost_volume_cw: the worklist kernel does not take this shape (D > 128 or very wide F)");
     }
     if (!handled) {
-        if (a->cost_hi || a->gate_bits) return fail(MAGNET_E_DIM, "magnet_cost_volume_cw: this shape falls back to the generic kernel, which has no split / gate-bit output");
+        if (a->cost_hi || a->gate_bits) return fail(MAGNET_E_SHAPE, "magnet_cost_volume_cw: this shape falls back to the generic kernel, which has no split / gate-bit output");
         e = magnet::launch_cv_generic(p, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw generic launch");
     }
@@ -316,7 +329,9 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     p.repad = a->repad;
     p.tail_w_hi = (const uint16_t*)a->tail_w_hi; p.tail_w_lo = (const uint16_t*)a->tail_w_lo; p.tail_bias = a->tail_bias;
     p.tail_cout = a->tail_cout_pad;
-    { static const int dev_variant = getenv("MAGNET_CONV_VARIANT") ? atoi(getenv("MAGNET_CONV_VARIANT")) : 0; p.variant = dev_variant; }   // dev A/B switch
+#ifdef MAGNET_DEV
+    { static const int dev_variant = getenv("MAGNET_CONV_VARIANT") ? atoi(getenv("MAGNET_CONV_VARIANT")) : 0; p.variant = dev_variant; }   // dev A/B switch (dev build only)
+#endif
     hipError_t e = magnet::launch_conv_mfma(p, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_conv_mfma launch");
 }

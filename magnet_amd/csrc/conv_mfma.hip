@@ -1455,7 +1455,11 @@ __global__ __launch_bounds__(256) void pack_split_wide_kernel(const float* __res
 
 hipError_t launch_pack_split(const float* in, uint16_t* out_hi, uint16_t* out_lo, int N, int C, int h, int w,
                              int ctot, int c_off, long long in_img_stride, hipStream_t s) {
+#ifdef MAGNET_DEV
     static const bool narrow = getenv("MAGNET_PACK_NARROW") != nullptr;      // dev A/B: the 64-pixel kernel
+#else
+    constexpr bool narrow = false;
+#endif
     if (!narrow && (h * w) % 4 == 0 && C % 8 == 0 && in_img_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
         const int bpw = (h * w + PW_PIX - 1) / PW_PIX;
         hipLaunchKernelGGL(pack_split_wide_kernel, dim3((unsigned)(N * bpw), (unsigned)((C + 63) / 64)), dim3(256), 0, s, in, out_hi, out_lo,

@@ -371,7 +371,11 @@ hipError_t launch_cv_fast64(const CvParams& p, hipStream_t stream, bool* handled
     *handled = true;
     if (p.feat_bf16) {
         if (nchunk == 8) {                                                                 // F = 64: 4 lanes x 32 B per (item, tap) unit
+#ifdef MAGNET_DEV
             static const int dev_minw = getenv("MAGNET_MATCH_MINW") ? atoi(getenv("MAGNET_MATCH_MINW")) : 0;   // dev: occupancy A/B
+#else
+            constexpr int dev_minw = 0;
+#endif
             if (dev_minw == 4) return launch_fast64<uint16_t, 2, true, 4, 4>(p, stream);
             if (dev_minw == 6) return launch_fast64<uint16_t, 2, true, 6, 4>(p, stream);
             if (dev_minw == 8) return launch_fast64<uint16_t, 2, true, 8, 4>(p, stream);

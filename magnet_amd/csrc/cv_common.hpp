@@ -16,11 +16,12 @@ struct CvParams {
     int tiles_x, tiles_y;
     int feat_bf16;
     int mode_f;                       // 1 = est_costvolume_F semantics (fixed bins, no gate, fp32 view sum)
-    int ablate;                       // dev-only timing ablations (path >> 8): 1 = skip P2 dots, 2 = skip gmm taps
+    int ablate;                       // MagnetCostVolumeArgs.dev_flags (0 unless built with -DMAGNET_DEV): timing ablations / kernel variants
     float kappa;
     const void*    ref_feat;
     const void*    src_feat;          // (V*B, h+2, w+2, F) channel-last, one-texel zero border
     const float*   src_gmm;           // (V*B, h+2, w+2, 2) interleaved [mu,sigma], one-texel zero border
+    const float*   src_gmq;           // optional (V*B, h+2, w+2, 8): the same map per QUAD origin in quad form (magnet_pack_gmm_quad)
     const float*   ref_gmm;
     const float*   d_volume;
     const float*   poses;
@@ -35,6 +36,7 @@ struct CvParams {
     long long      cost_ld;
     uint8_t*       gate_bits;         // optional debug output (B,V,D,h,w)
     int            npx;               // cost_volume_fast64.hip: pixels per wave (set by its launcher)
+    uint32_t       magic_tiles, magic_tiles_x;   // cost_volume_v3.hip: ceil(2^32 / (tiles_x * tiles_y)), ceil(2^32 / tiles_x) (set by its launcher)
     const double*  ray_params;        // optional (B,8) fx, fy, cx, cy, sx, sy, left, top: rays generated in the kernel
     float k[MAGNET_MAX_CANDIDATES];   // (float)k_j, read with wave-uniform indices (scalar loads)
 };
@@ -88,6 +90,7 @@ hipError_t launch_cv_worklist(const CvParams& p, hipStream_t stream, bool* handl
 hipError_t launch_cv_cand(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cv_fast64(const CvParams& p, hipStream_t stream, bool* handled);
+hipError_t launch_cv_v3(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cvf_bwd(const CvParams& p, const float* gout, float* grad_ref, float* grad_src, hipStream_t stream,
                           bool* handled);
 hipError_t launch_cvf_bwd_ref_only(const CvParams& p, const float* gout, float* grad_ref, hipStream_t stream, bool* handled);

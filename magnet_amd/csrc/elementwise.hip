@@ -135,6 +135,37 @@ hipError_t launch_pack_gmm(const float* in, float* out, int N, int h, int w, hip
     return hipGetLastError();
 }
 
+// (N,2,h,w) planar [mu,sigma] -> (N,h+2,w+2,8): the zero-bordered map per quad origin in quad form (one thread per origin):
+// v(bx,by) = v00 + bx*(v10-v00) + by*(v01-v00) + bx*by*((v11-v01)-(v10-v00))  — 3 fma per bilinear sample in the matcher
+__global__ __launch_bounds__(256) void pack_gmm_quad_kernel(const float* __restrict__ in, float4* __restrict__ out,
+                                                             int N, int h, int w) {
+    const int Wp = w + 2, Hp = h + 2;
+    const size_t total = (size_t)N * Hp * Wp;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x0 = (int)(i % Wp) - 1, y0 = (int)((i / Wp) % Hp) - 1;       // unpadded coordinates of the quad's top-left texel
+    const size_t n = i / ((size_t)Wp * Hp);
+    const size_t hw = (size_t)h * w;
+    float m[4], s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int x = x0 + (t & 1), y = y0 + (t >> 1);
+        const bool in_img = x >= 0 && x < w && y >= 0 && y < h;
+        const size_t o = (size_t)(in_img ? y : 0) * w + (in_img ? x : 0);
+        m[t] = in_img ? in[(n * 2 + 0) * hw + o] : 0.f;
+        s[t] = in_img ? in[(n * 2 + 1) * hw + o] : 0.f;
+    }
+    out[i * 2 + 0] = make_float4(m[0], m[1] - m[0], m[2] - m[0], (m[3] - m[2]) - (m[1] - m[0]));
+    out[i * 2 + 1] = make_float4(s[0], s[1] - s[0], s[2] - s[0], (s[3] - s[2]) - (s[1] - s[0]));
+}
+
+hipError_t launch_pack_gmm_quad(const float* in, float* out, int N, int h, int w, hipStream_t s) {
+    const size_t total = (size_t)N * (h + 2) * (w + 2);
+    hipLaunchKernelGGL(pack_gmm_quad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in,
+                       reinterpret_cast<float4*>(out), N, h, w);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack(const float* in, void* out, int N, int F, int h, int w, bool bf16, int pad, hipStream_t s) {
     const int hw = h * w;
     const int bpi = (hw + PK_PIX - 1) / PK_PIX;
@@ -146,7 +177,11 @@ hipError_t launch_pack(const float* in, void* out, int N, int F, int h, int w, b
         const unsigned nb = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(zero_border_kernel, dim3(nb), dim3(256), 0, s, reinterpret_cast<uint4*>(out), N, h, w, vec_per_tex);
     }
+#ifdef MAGNET_DEV
     static const bool narrow = getenv("MAGNET_PACK_NARROW") != nullptr;      // dev A/B: the 64-pixel kernel
+#else
+    constexpr bool narrow = false;
+#endif
     if (!narrow && hw % 4 == 0 && F % 8 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
         const int bpw = (hw + PKW_PIX - 1) / PKW_PIX;
         const dim3 gw((unsigned)(N * bpw), (unsigned)((F + 63) / 64));

@@ -14,7 +14,7 @@ Two entry points:
 """
 from __future__ import annotations
 
-import weakref
+import zlib
 
 import torch
 
@@ -29,20 +29,20 @@ _VALID_CACHE: dict = {}
 def _to_device_cached(t: torch.Tensor, device, dtype, cache: dict):
     if t.is_cuda:
         return t.to(device=device, dtype=dtype).contiguous()
-    # key on the CONTENT for small tensors (intM: 36 B per frame) and on a strided content sample for the ray table: a tensor
-    # from torch.from_numpy whose array is rewritten through numpy keeps data_ptr and _version
-    tc = t.contiguous()
-    flat = tc.view(-1)
-    sample = flat if flat.numel() <= 4096 else flat[:: max(1, flat.numel() // 1024)]
-    key = (t.data_ptr(), t._version, tuple(t.shape), str(device), dtype, bytes(sample.numpy().tobytes()),
-           float(flat[-1]) if flat.numel() else 0.0)
+    # Keyed on the CONTENT (a tensor from torch.from_numpy whose array is rewritten through numpy keeps data_ptr and
+    # _version): the bytes themselves for small tensors (intM: 36 B per frame), a crc32 + adler32 pair of the whole buffer for
+    # large ones (the ray table: ~1 ms per 15 MB, against the 15 MB upload it saves).  No identity test: a DataLoader hands
+    # over a fresh tensor with the same content every step and must hit.
+    buf = memoryview(t.contiguous().numpy()).cast("B")
+    digest = bytes(buf) if len(buf) <= 4096 else (zlib.crc32(buf), zlib.adler32(buf), len(buf))
+    key = (tuple(t.shape), str(t.dtype), str(device), dtype, digest)
     hit = cache.get(key)
-    if hit is not None and hit[0]() is t:
-        return hit[1]
-    if len(cache) > 64:
-        cache.clear()
+    if hit is not None:
+        return hit
+    if len(cache) >= 16:                      # bounded: at most 16 resident device copies (ray tables are ~15 MB each at B = 64)
+        cache.pop(next(iter(cache)))
     d = t.to(device=device, dtype=dtype).contiguous()
-    cache[key] = (weakref.ref(t), d)
+    cache[key] = d
     return d
 
 
@@ -97,7 +97,10 @@ class CostVolumeCW:
             self.V = nghbr_feat.shape[0] // self.B
             self.ref_cl = lib.pack_features(ref_feat.detach().float().contiguous(), self.fe, pad=0)
             self.src_pad = lib.pack_features(nghbr_feat.detach().float().contiguous(), self.fe, pad=1)
-        self.src_gmm_pad = lib.pack_gmm(nghbr_gmms.detach().float().contiguous())
+        g = nghbr_gmms.detach().float().contiguous()
+        self.src_gmm_pad = lib.pack_gmm(g)
+        # the production matcher for D > 32 reads the (mu, sigma) map per quad origin in quad form (3 fma per bilinear sample)
+        self.src_gmm_quad = lib.pack_gmm_quad(g) if (path & 0xff) in (0, 4) else None
         self.poses = nghbr_poses.detach().to(device=dev, dtype=torch.float32).contiguous()
         self.is_valid = _valid_to_device(is_valid, dev)
         self.intM = _to_device_cached(cam_intrins["intM"], dev, torch.float32, _INTRINS_CACHE)
@@ -125,7 +128,7 @@ class CostVolumeCW:
         res = lib.cost_volume_cw(self.ref_cl, self.src_pad, self.src_gmm_pad, self.poses, self.is_valid,
                                  self.intM, self.rays, self.kappa, ref_gmm=ref_gmm, k_list=k_list,
                                  d_volume=d_volume, out=out, path=self.path, stats=stats, out_split=out_split,
-                                 gate_bits=gate_bits, ray_params=self.ray_params)
+                                 gate_bits=gate_bits, ray_params=self.ray_params, src_gmm_quad=self.src_gmm_quad)
         if sink is not None:
             e1.record()
             sink.append((e0, e1))
@@ -184,6 +187,10 @@ def est_costvolume_F(d_center, ref_feat, nghbr_feat, R, t, is_valid, cam_intrins
     poses = _poses_from_Rt(R.detach().float(), t.detach().float()).to(dev).contiguous()
     iv = _valid_to_device(is_valid, dev)
     intM = _to_device_cached(cam_intrins["intM"], dev, torch.float32, _INTRINS_CACHE)
-    rays = _to_device_cached(cam_intrins["unit_ray_array_2D"], dev, torch.float32, _INTRINS_CACHE)
+    if "unit_ray_array_2D" in cam_intrins:
+        rays = _to_device_cached(cam_intrins["unit_ray_array_2D"], dev, torch.float32, _INTRINS_CACHE)
+    else:       # table-free dict (magnet_amd.data with_table=False): the F forward / backward read the table, build it on the device
+        rays = lib.make_rays(_to_device_cached(cam_intrins["ray_params"], dev, torch.float64, _INTRINS_CACHE),
+                             ref_feat.shape[2], ref_feat.shape[3])
     raw = _CostVolumeF.apply(ref_feat, nghbr_feat, bins, poses, iv, intM, rays, path, bwd_path)
     return torch.softmax(raw, dim=1)                                   # homography.py:45

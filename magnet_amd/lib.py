@@ -19,14 +19,23 @@ FEAT_F32, FEAT_BF16 = 0, 1
 MAX_CANDIDATES = 256
 
 API_SYMBOLS = ("magnet_version", "magnet_last_error", "magnet_device_count", "magnet_pack_features",
-               "magnet_pack_gmm",
+               "magnet_pack_gmm", "magnet_pack_gmm_quad",
                "magnet_cost_volume_cw", "magnet_cost_volume_f_backward", "magnet_cost_volume_f_backward_ws",
                "magnet_cost_volume_f_backward_workspace", "magnet_gaussian_update",
                "magnet_upsample_depth")
 
 
+# argument-error codes of include/magnet_hip.h (positive return values; negative = -(hipError_t))
+E_NULL, E_DIM, E_DTYPE, E_ALIGN, E_NODEVICE, E_SHAPE = 1, 2, 3, 4, 5, 6
+
+
 class MagnetError(RuntimeError):
-    pass
+    """code = the C ABI's return value when the error came from the library (None for host-side checks):
+    E_SHAPE = "this kernel / output form does not take the shape" (the only condition callers may fall back on)."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 class MagnetCostVolumeArgs(ctypes.Structure):
@@ -47,6 +56,8 @@ class MagnetCostVolumeArgs(ctypes.Structure):
         ("mode", ctypes.c_int32),
         ("gate_bits", ctypes.c_void_p),
         ("ray_params", ctypes.c_void_p),
+        ("src_gmm_quad", ctypes.c_void_p),
+        ("dev_flags", ctypes.c_uint32),
     ]
 
 
@@ -71,6 +82,8 @@ def load() -> ctypes.CDLL:
     lib.magnet_pack_features.argtypes = [P, P, I, I, I, I, I, I, P]
     lib.magnet_pack_gmm.restype = ctypes.c_int
     lib.magnet_pack_gmm.argtypes = [P, P, I, I, I, P]
+    lib.magnet_pack_gmm_quad.restype = ctypes.c_int
+    lib.magnet_pack_gmm_quad.argtypes = [P, P, I, I, I, P]
     lib.magnet_cost_volume_cw.restype = ctypes.c_int
     lib.magnet_cost_volume_cw.argtypes = [ctypes.POINTER(MagnetCostVolumeArgs), P]
     lib.magnet_cost_volume_f_backward.restype = ctypes.c_int
@@ -86,7 +99,7 @@ def load() -> ctypes.CDLL:
 def _check(rc: int, what: str):
     if rc != 0:
         msg = load().magnet_last_error().decode("utf-8", "replace")
-        raise MagnetError(f"{what} failed (rc={rc}): {msg}")
+        raise MagnetError(f"{what} failed (rc={rc}): {msg}", code=rc)
 
 
 def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
@@ -149,9 +162,24 @@ def pack_gmm(gmm_nchw: torch.Tensor, out: torch.Tensor | None = None):
     return out
 
 
+def pack_gmm_quad(gmm_nchw: torch.Tensor, out: torch.Tensor | None = None):
+    """(N,2,h,w) fp32 [mu,sigma] planes -> (N,h+2,w+2,8): the zero-bordered map per quad origin in quad form
+    (MagnetCostVolumeArgs.src_gmm_quad; the production matcher's bilinear (mu, sigma) samples are 3 fma each)."""
+    g = _dev(gmm_nchw, "gmm_nchw", torch.float32)
+    N, two, h, w = g.shape
+    if two != 2:
+        raise MagnetError(f"gmm_nchw must be (N,2,h,w), got {tuple(g.shape)}")
+    if out is None:
+        out = torch.empty((N, h + 2, w + 2, 8), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _check(load().magnet_pack_gmm_quad(g.data_ptr(), _dev(out, "out", torch.float32).data_ptr(), N, h, w, _stream(g)),
+               "magnet_pack_gmm_quad")
+    return out
+
+
 def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM, rays, kappa,
                    ref_gmm=None, k_list=None, d_volume=None, out=None, path: int = 0, stats=None, out_split=None,
-                   mode: int = 0, gate_bits=None, ray_params=None):
+                   mode: int = 0, gate_bits=None, ray_params=None, src_gmm_quad=None, dev_flags: int = 0):
     """Launch the fused matching kernel.  All tensors on one GPU; see MagnetCostVolumeArgs.
 
     ref_feat_cl (B,h,w,F) from pack_features(pad=0); src_feat_pad (V*B,h+2,w+2,F) from
@@ -235,7 +263,15 @@ def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM
         a.cost_batch_stride = out.stride(0) if B > 1 else 0
     if out_split is None:
         a.cost = out.data_ptr()
-    a.path = int(path)
+    # `path` = 0..4; for the dev tools' convenience bits 8.. of the python argument are forwarded as dev_flags (ignored by the
+    # product build of the library)
+    a.path = int(path) & 0xff
+    a.dev_flags = (int(path) >> 8) | int(dev_flags)
+    if src_gmm_quad is not None:
+        gq = _dev(src_gmm_quad, "src_gmm_quad", torch.float32)
+        if tuple(gq.shape) != (V * B, h + 2, w + 2, 8):
+            raise MagnetError(f"src_gmm_quad shape {tuple(gq.shape)}, expected {(V * B, h + 2, w + 2, 8)}")
+        a.src_gmm_quad = gq.data_ptr(); keep.append(gq)
     if stats is not None:
         a.stats = _dev(stats, "stats").data_ptr()
     if gate_bits is not None:

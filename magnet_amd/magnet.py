@@ -277,7 +277,9 @@ class MAGNET(nn.Module):
                 # the candidate-lane kernels write the D cost channels of the G-Net input buffer directly
                 try:
                     matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out_split=(gin_hi, gin_lo, ctot))  # MAGNET.py:153-164
-                except lib.MagnetError:
+                except lib.MagnetError as e:
+                    if e.code != lib.E_SHAPE:        # bad arguments / HIP failures are real errors: never retried on another path
+                        raise
                     split_out = False                # a shape only the generic kernel takes (V >= 26, very wide F): NCHW + repack
             if not split_out:
                 matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out=work["cost"])

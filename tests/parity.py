@@ -58,6 +58,16 @@ WORKLIST_RTOL = 2e-5
 GATE_FLIP_FRAC = 1e-5     # SURVEY.md §7 / VERDICT r1: allowed fraction of flipped consistency gates (production matcher)
 
 
+def allowed_flips(n_gate: int) -> int:
+    """Flipped gates allowed among n_gate samples at the contract RATE of GATE_FLIP_FRAC.  For the BASELINE shapes (millions of
+    gates) that is simply the fraction.  On the small edge-case shapes the expected count is ~1, and a count bound of 1 would fail
+    a kernel sitting exactly at the contract rate a third of the time: there the bound is the 99.9 % Poisson quantile of the
+    expected count (expected 1.2 -> 6 allowed; 0.02 -> 1)."""
+    from scipy.stats import poisson
+    lam = GATE_FLIP_FRAC * n_gate
+    return int(lam) if lam >= 20 else max(1, int(poisson.ppf(0.999, lam)))
+
+
 def assert_tolerant_parity(hip, orc, hip_gates=None, orc_gates=None, n_views=4, label="", sens=None, eps=0.0):
     """Production matcher (path 0/4).  With gate bits from both sides (B,V,D,h,w): the gate-flip fraction is <= 1e-5 (at
     least one flip is tolerated on tiny inputs) and every value outside the tolerance sits on an entry with a flipped gate.
@@ -79,7 +89,7 @@ def assert_tolerant_parity(hip, orc, hip_gates=None, orc_gates=None, n_views=4, 
         n_flip, n_gate = int(flipped.sum()), int(flipped.size)
         st["gate_flips"], st["gates"], st["gate_flip_frac"] = n_flip, n_gate, n_flip / n_gate
         print(f"[parity {label} production] {st}")
-        assert n_flip <= max(1, int(GATE_FLIP_FRAC * n_gate)), f"{label}: {st}"
+        assert n_flip <= allowed_flips(n_gate), f"{label}: {st} (allowed {allowed_flips(n_gate)})"
         unexplained = bad0 & ~flipped.any(axis=1)
         assert not unexplained.any(), f"{label}: {int(unexplained.sum())} entries differ without a flipped gate: {st}"
     else:

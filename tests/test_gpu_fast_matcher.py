@@ -101,19 +101,6 @@ def test_fast_vs_oracle_baseline_shapes(hip_lib, gpu, name, wlname, B, seed, fdt
     _check(inp, oracle.depth_sampling(3, wl.D), gpu, fdt=fdt, label=name)
 
 
-def test_fast_matrix_pipe_correlation_variant(hip_lib, gpu):
-    """bf16 F = 64: dev bit 8 moves the channel contraction from v_dot2c to the matrix pipe (measured slower: 4x the L1
-    accesses); same gates, same tolerance."""
-    wl = synth.WORKLOADS["C2"]
-    inp = synth.make_inputs(wl, B=1, seed=5, round_bf16=True)
-    k = oracle.depth_sampling(3, wl.D)
-    _check(inp, k, gpu, fdt="bf16", label="C2 mfma-corr", path=4 | 0x100)
-    a, ga = _run(inp, k, gpu, feat_dtype="bf16", path=4)
-    b, gb = _run(inp, k, gpu, feat_dtype="bf16", path=4 | 0x100)
-    assert torch.equal(ga, gb)
-    assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))         # same positions: fp32 re-association only
-
-
 def test_fast_ragged_grid_and_odd_D(hip_lib, gpu):
     wl = synth.Workload("ragged", "scannet", 13, 19, V=1, D=7, F=8)
     inp = synth.make_inputs(wl, B=3, seed=4)

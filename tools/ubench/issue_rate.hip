@@ -54,6 +54,9 @@ typedef __attribute__((ext_vector_type(4))) float f4;
 #define T_SUBF(i, j)     "v_sub_f32 %" #i ", %" #i ", %" #j "\n"
 #define T_SAND(i, j)     "s_and_b64 s[30:31], %20, %20\n"
 #define T_SBCNT(i, j)    "s_bcnt1_i32_b64 s30, %20\n"
+#define T_SBREV(i, j)    "s_brev_b64 s[30:31], %20\n"
+#define T_SADDC(i, j)    "s_add_u32 s30, %18, %19\ns_addc_u32 s31, %19, %18\n"
+#define T_SMOVX(i, j)    "s_mov_b64 s[32:33], exec\ns_mov_b64 exec, %20\ns_mov_b64 exec, s[32:33]\n"
 #define T_MIXVS(i, j)    "v_fma_f32 %" #i ", %" #i ", %16, %17\ns_and_b64 s[30:31], %20, %20\n"
 #define T_MIXRCP(i, j)   "v_fma_f32 %" #i ", %" #i ", %16, %17\nv_fma_f32 %" #j ", %" #j ", %16, %17\nv_fma_f32 %" #i ", %" #i ", %16, %17\nv_rcp_f32 %" #i ", %" #i "\n"
 
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void k_valu(u64* out, int nit, float cf, unsig
     u64 m64 = ((u64)s1i << 32) | s0i;
     const u64 t0 = __builtin_readcyclecounter();
     for (int it = 0; it < nit; ++it) {
-#define BODY(T) asm volatile(R4(I8(T)) : VREGS : INS : "vcc", "s30", "s31");
+#define BODY(T) asm volatile(R4(I8(T)) : VREGS : INS : "vcc", "scc", "s30", "s31", "s32", "s33");
         if (OP == 0) BODY(T_FMA)
         if (OP == 1) BODY(T_MUL)
         if (OP == 2) BODY(T_FMAC_S)
@@ -91,6 +94,9 @@ __global__ __launch_bounds__(256) void k_valu(u64* out, int nit, float cf, unsig
         if (OP == 20) BODY(T_SUBF)
         if (OP == 21) BODY(T_SAND)
         if (OP == 22) BODY(T_SBCNT)
+        if (OP == 25) BODY(T_SBREV)
+        if (OP == 26) BODY(T_SADDC)
+        if (OP == 27) BODY(T_SMOVX)
         if (OP == 23) BODY(T_MIXVS)
         if (OP == 24) BODY(T_MIXRCP)
         if (OP == 100) BODY(T_MBLO)
@@ -303,7 +309,8 @@ int main() {
     RUN_VALU(100, "v_mbcnt_lo_u32_b32", 32); RUN_VALU(101, "v_mbcnt_hi_u32_b32", 32);
     RUN_VALU(18, "v_readlane_b32", 32); RUN_VALU(19, "v_readfirstlane_b32", 32);
     RUN_VALU(102, "v_mad_u32_u24", 32); RUN_VALU(103, "v_lshl_add_u32", 32); RUN_VALU(104, "v_lshlrev_b32", 32); RUN_VALU(105, "v_add_u32", 32);
-    RUN_VALU(21, "s_and_b64", 32); RUN_VALU(22, "s_bcnt1_i32_b64", 32);
+    RUN_VALU(21, "s_and_b64", 32); RUN_VALU(22, "s_bcnt1_i32_b64", 32); RUN_VALU(25, "s_brev_b64", 32); RUN_VALU(26, "s_add_u32 + s_addc_u32 (per pair)", 32);
+    RUN_VALU(27, "s_mov exec save / set / restore (per triple)", 32);
     RUN_VALU(23, "v_fma + s_and alternating (per pair)", 32); RUN_VALU(24, "3 v_fma + 1 v_rcp (per 4)", 32);
     printf("# LDS: cycles per wave-instruction per SIMD; x1/4 = LDS-pipe cycles per instruction per CU when all 4 SIMDs stream\n");
     RUN_LDS(0, "ds_read_b128 broadcast"); RUN_LDS(1, "ds_read_b128 lane*16"); RUN_LDS(2, "ds_read_b128 4 runs of 16 lanes");
