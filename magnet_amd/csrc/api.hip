@@ -127,6 +127,7 @@ static int cv_prepare(const MagnetCostVolumeArgs* a, magnet::CvParams& p, bool b
     p.kappa = a->kappa;
 #ifdef MAGNET_DEV
     p.ablate = (int)(a->dev_flags & 0xffffffu);                    // development switches: never in the product build
+    { static const int forced = getenv("MAGNET_DEV_FLAGS") ? (int)strtol(getenv("MAGNET_DEV_FLAGS"), nullptr, 0) : 0; p.ablate |= forced; }   // dev: run the test-suite against a variant
 #else
     p.ablate = 0;
 #endif

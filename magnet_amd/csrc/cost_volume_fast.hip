@@ -351,7 +351,7 @@ hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled) 
     if ((size_t)(p.h + 2) * (p.w + 2) >= ((size_t)1 << 24)) return hipSuccess;               // 24-bit texel index
     if ((size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets
     if (fast_lds_bytes<64>(p) > 64 * 1024 || (p.D <= 32 && fast_lds_bytes<32>(p) > 64 * 1024)) return hipSuccess;   // absurd V (D <= 32: + the reference vectors)
-    if (p.src_gmq && (p.ablate & 0x100)) {                                                   // D > 32 with the quad-form (mu, sigma) map: round 3 kernel (WORK IN PROGRESS: dev bit 0x100 selects it)
+    if (p.src_gmq && !(p.ablate & 0x100)) {                                                  // D > 32 with the quad-form (mu, sigma) map: the round-3 kernel (dev bit 0x100: the round-2 kernels)
         const hipError_t e = launch_cv_v3(p, stream, handled);
         if (e != hipSuccess || *handled) return e;
     }

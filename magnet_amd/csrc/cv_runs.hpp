@@ -1,0 +1,79 @@
+// cv_runs.hpp — helpers shared by the run-based production matchers (cost_volume_v3.hip, cost_volume_v4.hip): wave-private LDS
+// access by 32-bit byte address, stores / selects under 64-bit scalar lane masks, the 4-lane DPP reduction, run bookkeeping.
+#pragma once
+#include "cv_fast_common.hpp"
+
+namespace magnet {
+
+typedef __attribute__((address_space(3))) unsigned char v3_lds_u8;
+// wave-private LDS is addressed by 32-bit byte addresses (the run slot address `raddr` is a per-lane value); clang vector
+// types, because HIP's float4 / uint4 classes have no address-space-3 assignment operators
+typedef float v3_f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t v3_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t v3_u32x2 __attribute__((ext_vector_type(2)));
+#define V3_LDS(T, a) (*reinterpret_cast<__attribute__((address_space(3))) T*>(a))
+__device__ __forceinline__ float4 v3_ld_f4(uint32_t a) { const v3_f32x4 v = V3_LDS(const v3_f32x4, a); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 v3_ld_u4(uint32_t a) { const v3_u32x4 v = V3_LDS(const v3_u32x4, a); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 v3_ld_u2(uint32_t a) { const v3_u32x2 v = V3_LDS(const v3_u32x2, a); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ uint32_t v3_ld_u1(uint32_t a) { return V3_LDS(const uint32_t, a); }
+__device__ __forceinline__ void v3_st_f4(uint32_t a, float4 v) { V3_LDS(v3_f32x4, a) = v3_f32x4{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void v3_st_u4(uint32_t a, uint4 v) { V3_LDS(v3_u32x4, a) = v3_u32x4{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void v3_st_u2(uint32_t a, uint2 v) { V3_LDS(v3_u32x2, a) = v3_u32x2{v.x, v.y}; }
+__device__ __forceinline__ void v3_st_u1(uint32_t a, uint32_t v) { V3_LDS(uint32_t, a) = v; }
+__device__ __forceinline__ void v3_st_f1(uint32_t a, float v) { V3_LDS(float, a) = v; }
+
+// Masked stores take the lane mask as a 64-bit SCALAR operand (no per-lane predicate has to be materialised): v3_st1_mask / v3_st2_mask below.
+
+// select by a 64-bit scalar lane mask (bit set -> t)
+__device__ __forceinline__ float v3_sel_f(uint64_t mask, float t, float f) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ uint32_t v3_sel_u(uint64_t mask, uint32_t t, uint32_t f) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(mask));
+    return r;
+}
+
+// sum over aligned groups of 4 lanes in two DPP adds (the generic helper costs a third instruction); the s_nop covers the
+// 2 wait states a DPP read needs after a VALU write of the same register (the assembler does not insert them in inline asm)
+__device__ __forceinline__ float v3_reduce4(float v) {
+    float t, r;
+    // volatile: a cross-lane operation must not be sunk into the divergent `if (sub == 0)` that consumes its result
+    asm volatile("s_nop 3\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(v));   // (the producer is a v_dot2c: hipcc itself leaves 3 wait states)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(t));
+    return r;
+}
+
+// Leaders (first lanes of runs, ballot L) whose run holds at least one open gate (ballot G; every G lane belongs to a run).
+// In bit-reversed order a run is [.., leader] with the leader on top: adding the run's gate bits to the all-ones run body
+// carries into the leader's (zero) position exactly when the body holds a gate bit; the leader's own gate bit is OR-ed in.
+__device__ __forceinline__ uint64_t v3_open_leaders(uint64_t G, uint64_t L) {
+    const uint64_t Gr = __builtin_bitreverse64(G), Lr = __builtin_bitreverse64(L);
+    const uint64_t Z = ~Lr;
+    const uint64_t S = (Gr & Z) + Z;
+    return __builtin_bitreverse64((S & Lr) | (Gr & Lr));
+}
+
+// s_and_saveexec form of the masked stores (2 scalar instructions around the store instead of 3)
+template <int OFF>
+__device__ __forceinline__ void v3_st1_mask(uint64_t mask, uint32_t addr, uint32_t val) {
+    uint64_t save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3 offset:%4\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(mask), "v"(addr), "v"(val), "n"(OFF) : "memory", "scc");
+}
+__device__ __forceinline__ void v3_st2_mask(uint64_t mask, uint32_t addr, uint32_t lo, uint32_t hi) {
+    uint64_t save;
+    const uint64_t val = ((uint64_t)hi << 32) | lo;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(mask), "v"(addr), "v"(val) : "memory", "scc");
+}
+
+
+// First open lane of every stretch of open gates inside a run (G = open gates, L = run leaders; a lane continues its
+// predecessor's stretch when that lane is open and the lane is no leader).  One item per such lane: a run whose gate opens,
+// closes and opens again is listed twice (same slot, same values — harmless), everything else once.  3 scalar instructions.
+__device__ __forceinline__ uint64_t v3_first_open(uint64_t G, uint64_t L) { return G & (~(G << 1) | L); }
+
+}  // namespace magnet

@@ -20,15 +20,10 @@ ld = (wl.D + 7) // 8 * 8 + 256
 hi = torch.zeros(B * (wl.h + 2) * (wl.w + 2), ld, dtype=torch.bfloat16, device=dev); lo = torch.zeros_like(hi)
 fdt = wl.feat_dtype
 # needs a dev build of the library (python -m magnet_amd.build --dev): bits 8.. of `path` travel as MagnetCostVolumeArgs.dev_flags
-R3 = 0x100 << 8                                       # dev flag 0x100: the round-3 kernel (work in progress); without it the round-2 production kernels run
-R2 = 0
-def _dev(vg, lnpx): return 4 | R2 | 0x4000 | ((vg - 1) << 9) | (lnpx << 11)
-M5, M6, M8, NP2, VG2 = 0x2000 << 8, 0x800 << 8, 0x1000 << 8, 0x4000 << 8, 0x8000 << 8
-VARIANTS = [("production (auto)", 0), ("round-3 kernel", R3), ("r3 without dot products (timing only)", R3 | (0x200 << 8)),
-            ("r3 without (mu,sigma) loads (timing only)", R3 | (0x400 << 8)),
-            ("r3 dots without feature loads (timing only)", R3 | (0x10000 << 8)), ("r3 feature loads without dots (timing only)", R3 | (0x20000 << 8)),
-            ("r3 5 waves", R3 | M5), ("r3 5 waves, 2 passes in flight", R3 | M5 | NP2), ("r3 5 waves, VG=2, 2 passes", R3 | M5 | VG2 | NP2),
-            ("r3 6 waves, VG=2, 2 passes", R3 | M6 | VG2 | NP2), ("exact cand", 2), ("production (auto), again", 0)]
+R2 = 0x100 << 8                                       # dev flag 0x100: the round-2 production kernels although the quad map is given
+M4, M8, NP2, NP3, NP4 = 0x2000 << 8, 0x1000 << 8, 0x4000 << 8, 0x40000 << 8, 0x80000 << 8
+VARIANTS = [("production (auto) = round-3 kernel", 0), ("r3 3 passes in flight", NP3), ("r3 4 passes in flight", NP4), ("r3 compiled for 8 waves", M8 | NP2),
+            ("r3 without dot products (timing only)", 0x200 << 8), ("round-2 kernel (fast64)", 4 | R2), ("exact cand", 2), ("production (auto), again", 0)]
 for name, path in VARIANTS:
     if split and (path & 0xff) == 3:
         continue
