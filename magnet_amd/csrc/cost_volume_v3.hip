@@ -349,6 +349,10 @@ template <typename FeatT, int CPL, bool FULL, int MINW, int LPU>
 static hipError_t launch_v3(const CvParams& p, hipStream_t stream) {
     int vg = p.V >= 4 ? 4 : p.V;
     if (p.V > 4 && p.V % 4 != 0 && (p.V % 3 == 0 || p.V % 4 < p.V % 3)) vg = 3;
+#ifdef MAGNET_DEV
+    if (p.ablate & 0x400000) vg = 2;                                                     // dev: views per group
+    if (p.ablate & 0x800000) vg = 1;
+#endif
     switch (vg) {
         case 1: return launch_v3_v<FeatT, CPL, FULL, MINW, LPU, 1>(p, stream);
         case 2: return launch_v3_v<FeatT, CPL, FULL, MINW, LPU, 2>(p, stream);

@@ -22,8 +22,10 @@ fdt = wl.feat_dtype
 # needs a dev build of the library (python -m magnet_amd.build --dev): bits 8.. of `path` travel as MagnetCostVolumeArgs.dev_flags
 R2 = 0x100 << 8                                       # dev flag 0x100: the round-2 production kernels although the quad map is given
 M4, M8, NP2, NP3, NP4 = 0x2000 << 8, 0x1000 << 8, 0x4000 << 8, 0x40000 << 8, 0x80000 << 8
-VARIANTS = [("production (auto) = round-3 kernel", 0), ("r3 3 passes in flight", NP3), ("r3 4 passes in flight", NP4), ("r3 compiled for 8 waves", M8 | NP2),
-            ("r3 without dot products (timing only)", 0x200 << 8), ("round-2 kernel (fast64)", 4 | R2), ("exact cand", 2), ("production (auto), again", 0)]
+VG2, VG1 = 0x400000 << 8, 0x800000 << 8
+VARIANTS = [("production (auto) = round-3 kernel", 0), ("r3 VG=2 (68 registers)", VG2), ("r3 VG=1 (59 registers)", VG1), ("r3 3 passes in flight", NP3),
+            ("r3 compiled for 8 waves", M8 | NP2), ("r3 without dot products (timing only)", 0x200 << 8), ("round-2 kernel (fast64)", 4 | R2), ("exact cand", 2),
+            ("production (auto), again", 0)]
 for name, path in VARIANTS:
     if split and (path & 0xff) == 3:
         continue
