@@ -116,8 +116,17 @@ def make_poses(camera: str, B: int, V: int, gen: torch.Generator) -> torch.Tenso
     return poses.to(torch.float32)
 
 
+def _box(x: torch.Tensor, r: int, passes: int = 2) -> torch.Tensor:
+    """(2r+1)^2 box filter applied `passes` times to every (h, w) plane of x (zero padding): a cheap low-pass."""
+    k = torch.ones(1, 1, 2 * r + 1, 2 * r + 1) / float((2 * r + 1) ** 2)
+    y = x.reshape(-1, 1, x.shape[-2], x.shape[-1])
+    for _ in range(passes):
+        y = torch.nn.functional.conv2d(y, k, padding=r)
+    return y.reshape(x.shape)
+
+
 def make_inputs(wl: Workload, B: int, seed: int = 0, smooth_feats: bool = False,
-                invalid=(), round_bf16: bool | None = None):
+                invalid=(), round_bf16: bool | None = None, smooth: int = 0):
     """Inputs of `est_costvolume_CW` plus the D-Net side tensors the loop needs.
 
     Returns a dict of CPU tensors:
@@ -127,6 +136,10 @@ def make_inputs(wl: Workload, B: int, seed: int = 0, smooth_feats: bool = False,
     `invalid` is a list of (b, v) pairs to mark is_valid=0.
     `round_bf16` (default: wl.feat_dtype == 'bf16') rounds features to bf16 and back, which is
     the parity definition for bf16 storage (oracle sees the rounded values).
+    `smooth` = r > 0: the SMOOTH variant (SURVEY.md §8d "optionally smooth ... so bilinear taps are correlated"): features
+    low-passed by two passes of a (2r+1)^2 box and rescaled to unit variance, (mu, sigma) maps low-passed the same way around
+    their range centre — what real F-Net / D-Net outputs look like (neighbouring texels correlated), against the default
+    white-noise maps in which a 1e-5 texel shift of the sample position already moves a 64-channel score by 1e-4.
     """
     gen = torch.Generator().manual_seed(seed)
     c = CAMERAS[wl.camera]
@@ -138,6 +151,11 @@ def make_inputs(wl: Workload, B: int, seed: int = 0, smooth_feats: bool = False,
         sm = lambda x: torch.nn.functional.conv2d(
             x.reshape(-1, 1, h, w), k, padding=1).reshape(x.shape)
         ref_feat, nghbr_feat = sm(ref_feat), sm(nghbr_feat)
+    if smooth > 0:
+        def lp(x):
+            y = _box(x, smooth)
+            return y / y.std().clamp_min(1e-6)
+        ref_feat, nghbr_feat = lp(ref_feat), lp(nghbr_feat)
     if round_bf16 is None:
         round_bf16 = wl.feat_dtype == "bf16"
     if round_bf16:
@@ -147,6 +165,13 @@ def make_inputs(wl: Workload, B: int, seed: int = 0, smooth_feats: bool = False,
     def gmm(n):
         mu = torch.rand(n, 1, h, w, generator=gen) * (c["mu"][1] - c["mu"][0]) + c["mu"][0]
         sg = torch.rand(n, 1, h, w, generator=gen) * (c["sigma"][1] - c["sigma"][0]) + c["sigma"][0]
+        if smooth > 0:       # smooth depth / uncertainty maps with the same range: blur the deviation from the range centre, restore its scale
+            def lpr(x, lo, hi):
+                mid, dev = 0.5 * (lo + hi), x - 0.5 * (lo + hi)
+                y = _box(dev, smooth)
+                y = y * (0.5 * (hi - lo) / y.abs().max().clamp_min(1e-6))
+                return mid + y
+            mu, sg = lpr(mu, *c["mu"]), lpr(sg, *c["sigma"])
         return torch.cat([mu, sg], dim=1)
 
     ref_gmms = gmm(B)

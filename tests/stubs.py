@@ -66,6 +66,23 @@ def train_case():
     return args, ref_img, nghbr_imgs, poses, valid, intr, gt, gt_mask
 
 
+def g13_case():
+    """Inputs of the D = 64 full-forward golden vector G13 (tests/golden/make_golden_r3.py): 240 x 320 images -> 60 x 80 grid,
+    B = 2 reference frames, V = 4 source views (one invalid), D = 64, I = 3, F = 64 — regenerated from seeds by the test."""
+    from magnet_amd import synth
+    args = make_args(D=64, iters=3, dpv_h=60, dpv_w=80)
+    gen = torch.Generator().manual_seed(131)
+    B, V = 2, 4
+    ref_img = torch.rand(B, 3, 240, 320, generator=gen)
+    nghbr_imgs = torch.rand(V * B, 3, 240, 320, generator=gen)
+    poses = synth.make_poses("scannet", B, V, gen)
+    valid = torch.ones(B, V, dtype=torch.int32); valid[1, 2] = 0
+    intr = synth.make_intrinsics("scannet", 60, 80, B)
+    # gain 0.3 on the seeded G-Net weights: sigma stays O(0.1) and mu moves by ~1 % per iteration (with gain 1 sigma collapses to 1e-3 after the
+    # first update and the later iterations' gates are almost all closed — a vacuous check of the matcher)
+    return args, ref_img, nghbr_imgs, poses, valid, intr, dict(d=121, f=122, w=123, gain=0.3)
+
+
 def magnet_nll_loss(pred_list, gt_depth, gt_mask, gamma=0.8):
     """The reference's training loss for MaGNet (utils/losses.py:28-52, 'gaussian'): gamma-weighted mean NLL of every
     iteration's (mu, sigma) against the ground truth at the valid pixels.  Test-side restatement (losses are outside the

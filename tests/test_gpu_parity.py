@@ -316,9 +316,11 @@ def test_full_loop_abs_rel_C3_shape(hip_lib, gpu, backend):
     torch-CPU G-Net + oracle tail/upsample) on identical inputs: abs_rel delta < 1e-4."""
     from magnet_amd.magnet import MAGNET
     wl = synth.WORKLOADS["C3"]
-    inp = synth.make_inputs(wl, B=1, seed=0)
+    inp = synth.make_inputs(wl, B=1, seed=0, round_bf16=False)          # the HAND-OVER is fp32 (what an F-Net produces) ...
     args = make_args(D=wl.D, iters=3, dpv_h=wl.h, dpv_w=wl.w)
     m = MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2), feat_dtype="bf16", conv_backend=backend)
+    # ... the kernel stores bf16 (round to nearest even), so the oracle is fed exactly those rounded values (SURVEY.md section 7)
+    inp_orc = dict(inp, ref_feat=inp["ref_feat"].to(torch.bfloat16).float(), nghbr_feat=inp["nghbr_feat"].to(torch.bfloat16).float())
     seeded_magnet_weights(m, seed=5)
     x_d3 = torch.randn(1, 256, wl.h, wl.w, generator=torch.Generator().manual_seed(7)) * 0.5
     # oracle loop on the CPU
@@ -327,7 +329,7 @@ def test_full_loop_abs_rel_C3_shape(hip_lib, gpu, backend):
     with torch.no_grad():
         mask = m.mask_head(x_d3)
         for _ in range(3):
-            cost = torch.from_numpy(oracle_cost(dict(inp, ref_gmms=gmm), k))
+            cost = torch.from_numpy(oracle_cost(dict(inp_orc, ref_gmms=gmm), k))
             raw = m.g_net.gnet(torch.cat([cost, x_d3], dim=1))
             gmm = torch.from_numpy(oracle.gaussian_update(raw.numpy(), gmm.numpy()))
             cpu_preds.append(oracle.upsample_depth_via_mask(gmm.numpy(), mask.numpy(), 4))
