@@ -108,21 +108,103 @@ def cpu_baseline(wl, model_cpu, iters, budget_s=15.0):
             "matcher_only_frames_per_s": 1.0 / tm}
 
 
-def spawn_ranks(n: int) -> int:
+def live_counters(wl, B, fdt, timeout_s=150):
+    """rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ instruction counters: separate runs, as the guide
+    prescribes) over `bench.py --kernel-only` of the same workload, in child processes.  HBM bytes per launch =
+    FETCH_SIZE [KB] x 1024 x 2.0 (gfx950 tallies 128-byte read requests at 64 B: MI355X_MICROARCH.md, HBM) + WRITE_SIZE [KB] x 1024
+    (x 1.000 on a 1 GiB device copy: profiles/r1, r2).  Returns (traffic_bytes, source_text, sq_dict) or (None, None, None)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, None, None
+    passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
+              "SQ": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]}
+    vals = {}
+    for tag, ctrs in passes.items():
+        tmp = tempfile.mkdtemp(prefix="magnet_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", tmp, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--kernel-only", "--no-pmc", "--no-cpu-baseline", "--sustain-s", "0",
+               "--steps", "3", "--warmup", "1", "--workload", wl.name, "--frames", str(B), "--feat-dtype", fdt]
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k_, None)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            acc = {}
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "cv_" in r["Kernel_Name"] and "_kernel" in r["Kernel_Name"]:
+                        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for c_, v_ in acc.items():
+                vals[c_] = sum(v_) / len(v_)
+        except Exception as e:                                   # profiler missing / hung / refused: report nothing rather than a stale number
+            print(f"[bench] rocprofv3 pass {tag} failed ({type(e).__name__}); traffic / counters omitted", file=sys.stderr)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    traffic = src = sq = None
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        traffic = float(f"{vals['FETCH_SIZE'] * 1024 * 2.0 + vals['WRITE_SIZE'] * 1024:.4g}")
+        src = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --kernel-only` of this "
+               "workload; FETCH_SIZE x 2.0 (gfx950 correction), WRITE_SIZE x 1.0; mean per launch")
+    if "SQ_INSTS_VALU" in vals:
+        iters = float(B * wl.h * wl.w * wl.V)                                    # (pixel, view) wave iterations per launch
+        sq = {"valu_insts_per_pixel_view": round(vals["SQ_INSTS_VALU"] / iters, 2), "salu_insts_per_pixel_view": round(vals.get("SQ_INSTS_SALU", 0) / iters, 2),
+              "vmem_insts_per_pixel_view": round(vals.get("SQ_INSTS_VMEM_RD", 0) / iters, 2), "lds_insts_per_pixel_view": round(vals.get("SQ_INSTS_LDS", 0) / iters, 2),
+              "wave_cycles_waiting_frac": round(vals.get("SQ_WAIT_ANY", 0) / max(vals.get("SQ_WAVE_CYCLES", 1), 1), 3)}
+    return traffic, src, sq
+
+
+def spawn_ranks(n: int, poll_s: float = 0.2, grace_s: float = 5.0) -> int:
     """Re-run this command line as n processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, one GPU
-    each via LOCAL_RANK -> torch.cuda.set_device) and wait for them.  Rank 0's stdout (the JSON line) passes through."""
+    each via LOCAL_RANK -> torch.cuda.set_device), as the reference spawns its DDP workers (train_MaGNet.py:323-338).
+    Rank 0's stdout (the JSON line) passes through; every rank's stderr passes through tagged "[rank r]"; the stdout of
+    ranks > 0 is forwarded to stderr with the same tag.  ALL children are polled: the first one that exits non-zero (or is
+    killed) takes the others down (SIGTERM, SIGKILL after `grace_s`) — a dead rank must not leave the rest waiting in an
+    RCCL barrier until the collective timeout — and its return code is this launcher's."""
     import socket
     import subprocess
+    import threading
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-    procs = []
+    procs, pumps = [], []
+
+    def pump(stream, tag):
+        for line in iter(stream.readline, ""):
+            sys.stderr.write(f"{tag} {line}" if line.strip() else line)
+        stream.close()
+
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for pr in procs:
-        rc = rc or pr.wait()
+        pr = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, text=True, bufsize=1,
+                              stdout=None if r == 0 else subprocess.PIPE, stderr=subprocess.PIPE)
+        procs.append(pr)
+        for st in ([pr.stderr] if r == 0 else [pr.stderr, pr.stdout]):
+            t = threading.Thread(target=pump, args=(st, f"[rank {r}]"), daemon=True); t.start(); pumps.append(t)
+    rc, alive = 0, set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code                  # killed by signal s -> 128 + s
+                sys.stderr.write(f"[bench launcher] rank {r} exited with {code}: stopping the other {len(alive)} rank(s)\n")
+                for o in alive:
+                    procs[o].terminate()
+                t_end = time.monotonic() + grace_s
+                while time.monotonic() < t_end and any(procs[o].poll() is None for o in alive):
+                    time.sleep(poll_s)
+                for o in alive:
+                    if procs[o].poll() is None:
+                        procs[o].kill()
+        if alive:
+            time.sleep(poll_s)
+    for t in pumps:
+        t.join(timeout=2.0)
     return rc
 
 
@@ -141,10 +223,13 @@ def dry_run(a, rank, world):
     for _ in range(a.steps):
         pass
     mdist.barrier()
-    elapsed = mdist.max_over_ranks(time.perf_counter() - t0)
+    mine = time.perf_counter() - t0
+    elapsed = mdist.max_over_ranks(mine)
+    per_rank = mdist.gather_floats((hi - lo) * a.steps / max(mine, 1e-9))
     frames = mdist.sum_over_ranks(hi - lo)
     if rank == 0:
         print(json.dumps({"metric": "dry-run (launcher self-test, no kernels)", "value": None, "unit": "ref-frames/s",
+                          "per_rank_frames_per_s": per_rank,
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / max(1, a.steps),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": wl.name, "frames_per_step_all_ranks": int(frames),
@@ -172,10 +257,13 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="run the mask head on a side stream (measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-only", action="store_true", help="step = the fused cost-volume kernel alone")
+    ap.add_argument("--nchw-out", action="store_true", help="--kernel-only: write the reference's (B,D,h,w) fp32 volume instead of the "
+                    "split-bf16 channel-last form the step uses (the G-Net input buffer)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--packed-inputs", action="store_true", help="backbone outputs arrive in the kernels' layouts (features "
                     "channel-last as the matrix-core F-Net writes them, x_d3 in the G-Net input buffer): no pack pass in the step")
     ap.add_argument("--overlap-pack", action="store_true", help="x_d3 repack on a side stream beside the matcher (measured: no gain)")
-    ap.add_argument("--sustain-s", type=float, default=2.0, help="extra untimed-by-contract run of this many seconds after the K "
+    ap.add_argument("--sustain-s", type=float, default=6.0, help="extra untimed-by-contract run of this many seconds after the K "
                     "steps, reported as sustained_frames_per_s (0 = skip)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / distributed self-test without a GPU: gloo backend, "
                     "the step is a no-op (used by tests/test_bench_launcher.py)")
@@ -186,6 +274,8 @@ def main():
         # DDP workers the same way, train_MaGNet.py:323-338); under torch.distributed.run the environment is already set
         raise SystemExit(spawn_ranks(a.gpus))
 
+    if os.environ.get("MAGNET_BENCH_FAIL_RANK") == os.environ.get("RANK", "0") and a.dry_run:
+        raise SystemExit(3)                                  # launcher self-test (tests/test_bench_launcher.py): this rank dies early
     rank, world, local = mdist.init_from_env(backend="gloo" if a.dry_run else None)
     if world != a.gpus and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -232,11 +322,16 @@ def main():
     if a.kernel_only:
         matcher = CostVolumeCW(inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"],
                                inp["is_valid"], inp["cam_intrins"], 5, feat_dtype=fdt, path=a.path)
-        out = torch.empty(B, wl.D, wl.h, wl.w, device=device)
+        if a.nchw_out:
+            kw = dict(out=torch.empty(B, wl.D, wl.h, wl.w, device=device))
+        else:                                               # the form the step uses: the D cost channels of the G-Net input buffer
+            ld = (wl.D + 7) // 8 * 8 + 256
+            hi = torch.zeros(B * (wl.h + 2) * (wl.w + 2), ld, dtype=torch.bfloat16, device=device)
+            kw = dict(out_split=(hi, torch.zeros_like(hi), ld))
 
         def step(timed):
             CostVolumeCW.event_sink = ev_pairs if timed else None   # HIP events around the fused kernel
-            matcher(ref_gmm=inp["ref_gmms"], k_list=k_list, out=out)
+            matcher(ref_gmm=inp["ref_gmms"], k_list=k_list, **kw)
     elif a.graph:
         from magnet_amd.graph import GraphedRefine
         graphed = GraphedRefine(model, inp["ref_gmms"], inp["x_d3"], inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"],
@@ -272,8 +367,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(True)
-    torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0                          # this rank's own time for its K steps (before the closing barrier)
+    mdist.barrier(); torch.cuda.synchronize()
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, device=device)
+    per_rank = mdist.gather_floats(B * a.steps / max(mine, 1e-9), device=device)   # a straggler GPU shows here, not only in the max
 
     # steady state: the contract's K steps take ~0.2 s, before the chip has settled at its sustained clock under continuous
     # matrix-core load; run on for --sustain-s seconds (outside the contract's timed region) and report that rate too
@@ -313,19 +411,12 @@ def main():
         packed_ms = mdist.max_over_ranks(1e3 * (time.perf_counter() - t_p) / a.steps, device=device)
 
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev_pairs) / max(1, len(ev_pairs))
-    # HBM traffic of the fused kernel comes from separate rocprofv3 --pmc passes (tools/profile_round.sh),
-    # committed under profiles/; bench.py cannot collect counters itself, so it quotes that record
-    # when (and only when) it was taken on this exact workload and batch.
+    # HBM traffic and instruction counters of the fused kernel: measured LIVE by separate rocprofv3 --pmc passes over a
+    # kernel-only child run of this same workload (rank 0, one GPU, production path only; null when the profiler is not
+    # available or a pass fails — never a stored number)
     traffic, traffic_src, pmc = None, None, None
-    try:
-        rec = json.load(open(os.path.join(REPO, "profiles", "r2", "traffic_C2.json")))
-        if wl.name == "C2" and B == 64 and fdt == "bf16" and a.path == 0 and rec.get("kernel", "").startswith("cv_fast64"):
-            traffic = rec["traffic_bytes_per_launch"]
-            traffic_src = ("profiles/r2/traffic_C2.json: separate rocprofv3 --pmc passes over this command by tools/profile_round.sh "
-                           "(FETCH_SIZE x 2.0 on gfx950 + WRITE_SIZE x its calibration on a 1 GiB copy)")
-            pmc = rec.get("sq")
-    except Exception:
-        pass
+    if rank == 0 and world == 1 and not a.no_pmc and not a.kernel_only and a.path == 0:
+        traffic, traffic_src, pmc = live_counters(wl, B, fdt)
     alg_bytes = wl.algorithmic_bytes() * B
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     frames = world * B * a.steps
@@ -365,9 +456,11 @@ def main():
             "ms_per_step_inputs_in_kernel_layouts": packed_ms,
             "frames_per_s_inputs_in_kernel_layouts": (world * B / (packed_ms * 1e-3)) if packed_ms else None,
             "weight_broadcast_bytes": bcast_bytes,
+            "per_rank_frames_per_s": per_rank,
+            "per_rank_min_max": [min(per_rank), max(per_rank)],
         }
         if pmc:
-            res["roofline"]["sq_counters"] = pmc            # VALU utilisation / instructions per (pixel, view): profiles/r2
+            res["roofline"]["sq_counters"] = pmc            # instructions per (pixel, view), wait fraction: measured in this run
         if c3:
             t3 = sum(t for t, _ in c3) / len(c3); f3 = sum(f for _, f in c3) / len(c3)
             res["roofline_conv"] = {

@@ -67,7 +67,8 @@ typedef struct MagnetCostVolumeArgs {
                                               (magnet_pack_features, pad = 1): grid_sample's zeros padding
                                               (homography.py:150) becomes plain loads */
     const float   *src_gmm_pad;            /* (V*B, h+2, w+2, 2) interleaved source [mu, sigma], zero border
-                                              (magnet_pack_gmm) */
+                                              (magnet_pack_gmm).  May be NULL when src_gmm_quad is given: a call that ends up in a
+                                              kernel that reads this layout then returns MAGNET_E_SHAPE */
     const float   *ref_gmm;                /* (B, 2, h, w) reference [mu, sigma]; used when d_volume == NULL */
     const double  *k_list;                 /* HOST, D float64 quantile offsets (MAGNET.depth_sampling, MAGNET.py:120-128);
                                               used when d_volume == NULL: d_j = mu + sigma*(float)k_j */

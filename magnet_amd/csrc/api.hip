@@ -90,7 +90,7 @@ MAGNET_API int magnet_pack_gmm_quad(const float* gmm_nchw, float* out_quad, int3
 // argument checks + launch parameters shared by the matcher and the backward of its mode 1
 static int cv_prepare(const MagnetCostVolumeArgs* a, magnet::CvParams& p, bool backward) {
     if (!a) return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: args is NULL");
-    if (!a->ref_feat_cl || !a->src_feat_pad || (!a->src_gmm_pad && a->mode != 1) || !a->poses || !a->is_valid || !a->intM ||
+    if (!a->ref_feat_cl || !a->src_feat_pad || (!a->src_gmm_pad && !a->src_gmm_quad && a->mode != 1) || !a->poses || !a->is_valid || !a->intM ||
         (!a->rays && !a->ray_params) || (!backward && !a->cost && !a->cost_hi))
         return fail(MAGNET_E_NULL, "magnet_cost_volume_cw: a required pointer is NULL");
     if (!a->rays && (backward || a->path == 3))
@@ -166,6 +166,9 @@ MAGNET_API int magnet_cost_volume_cw(const MagnetCostVolumeArgs* a, void* stream
             return fail(MAGNET_E_SHAPE, "magnet_cost_volume_cw: the production matcher needs fused sampling (d_volume == NULL), mode 0, "
                                       "stats == NULL and F*sizeof(feature) <= 512");
     }
+    if (!handled && !a->src_gmm_pad && a->mode != 1)      // only the quad-form (mu, sigma) map was given and the kernel that reads it does not take this call
+        return fail(MAGNET_E_SHAPE, "magnet_cost_volume_cw: this shape / path reads src_gmm_pad (magnet_pack_gmm); src_gmm_quad alone serves the "
+                                    "production matcher for D > 32 only");
     if (!handled && (path == 0 || path == 2)) {
         e = magnet::launch_cv_cand(p, (hipStream_t)stream, &handled);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_cw candidate-lane launch");

@@ -347,6 +347,7 @@ static hipError_t launch_fast_c(const CvParams& p, hipStream_t stream) {
 hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled) {
     *handled = false;
     if (p.d_volume || p.mode_f || p.stats) return hipSuccess;
+    const bool have_gmm = p.src_gmm != nullptr;               // the round-2 kernels below read the interleaved map
     const size_t esz = p.feat_bf16 ? 2 : 4;
     if ((size_t)(p.h + 2) * (p.w + 2) >= ((size_t)1 << 24)) return hipSuccess;               // 24-bit texel index
     if ((size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets
@@ -355,6 +356,7 @@ hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled) 
         const hipError_t e = launch_cv_v3(p, stream, handled);
         if (e != hipSuccess || *handled) return e;
     }
+    if (!have_gmm) return hipSuccess;                                                         // (api.hip reports MAGNET_E_SHAPE)
     if ((p.ablate & 0xff) == 0 || (p.ablate & 0x40)) {                                                 // (bit 15 with bit 14: fast64 dev variant)                                                 // D > 32: views batched per pixel (cost_volume_fast64.hip)
         const hipError_t e = launch_cv_fast64(p, stream, handled);
         if (e != hipSuccess || *handled) return e;

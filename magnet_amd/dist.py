@@ -82,6 +82,16 @@ def sum_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def gather_floats(value: float, device=None) -> list:
+    """[value of rank 0, ..., value of rank world-1] on every rank (one tiny all_gather)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

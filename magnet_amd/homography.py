@@ -14,6 +14,7 @@ Two entry points:
 """
 from __future__ import annotations
 
+import weakref
 import zlib
 
 import torch
@@ -26,23 +27,45 @@ _INTRINS_CACHE: dict = {}
 _VALID_CACHE: dict = {}
 
 
+_SMALL_BYTES = 1 << 20
+
+
 def _to_device_cached(t: torch.Tensor, device, dtype, cache: dict):
+    """Device copy of a CPU tensor the caller hands over on every call (cam_intrins, homography.py:89-90 re-uploads them).
+    <= 1 MB (intM; ray tables of small batches): keyed on a digest of the WHOLE content — a fresh tensor with the same content
+    (what a DataLoader hands over every step) hits, an in-place edit anywhere misses.
+    Larger (the ray table of a big batch, ~15 MB at B = 64: hashing it would cost milliseconds per call): keyed on the tensor
+    OBJECT (weakref identity + data_ptr + _version) plus a strided content sample; a different object never hits, entries whose
+    tensor has died are dropped, at most 4 large copies stay resident."""
     if t.is_cuda:
         return t.to(device=device, dtype=dtype).contiguous()
-    # Keyed on the CONTENT (a tensor from torch.from_numpy whose array is rewritten through numpy keeps data_ptr and
-    # _version): the bytes themselves for small tensors (intM: 36 B per frame), a crc32 + adler32 pair of the whole buffer for
-    # large ones (the ray table: ~1 ms per 15 MB, against the 15 MB upload it saves).  No identity test: a DataLoader hands
-    # over a fresh tensor with the same content every step and must hit.
-    buf = memoryview(t.contiguous().numpy()).cast("B")
-    digest = bytes(buf) if len(buf) <= 4096 else (zlib.crc32(buf), zlib.adler32(buf), len(buf))
-    key = (tuple(t.shape), str(t.dtype), str(device), dtype, digest)
-    hit = cache.get(key)
-    if hit is not None:
-        return hit
-    if len(cache) >= 16:                      # bounded: at most 16 resident device copies (ray tables are ~15 MB each at B = 64)
-        cache.pop(next(iter(cache)))
-    d = t.to(device=device, dtype=dtype).contiguous()
-    cache[key] = d
+    nbytes = t.numel() * t.element_size()
+    if nbytes <= _SMALL_BYTES:
+        buf = memoryview(t.contiguous().numpy()).cast("B")
+        digest = bytes(buf) if len(buf) <= 4096 else (zlib.crc32(buf), zlib.adler32(buf), len(buf))
+        key = ("small", tuple(t.shape), str(t.dtype), str(device), dtype, digest)
+        hit = cache.get(key)
+        if hit is not None:
+            return hit[1]
+        d = t.to(device=device, dtype=dtype).contiguous()
+        cache[key] = (None, d)
+    else:
+        flat = t.reshape(-1)
+        sample = flat[:: max(1, flat.numel() // 1024)]
+        key = ("large", t.data_ptr(), t._version, tuple(t.shape), str(t.dtype), str(device), dtype, bytes(sample.contiguous().numpy().tobytes()))
+        hit = cache.get(key)
+        if hit is not None and hit[0]() is t:
+            return hit[1]
+        for k_ in [k_ for k_, v_ in cache.items() if k_[0] == "large" and (v_[0]() is None or k_ == key)]:
+            del cache[k_]                                       # dead owners, and a stale entry of this key
+        large = [k_ for k_ in cache if k_[0] == "large"]
+        while len(large) >= 4:
+            del cache[large.pop(0)]
+        d = t.to(device=device, dtype=dtype).contiguous()
+        cache[key] = (weakref.ref(t), d)
+    if len(cache) > 64:
+        for k_ in list(cache)[:32]:
+            del cache[k_]
     return d
 
 
@@ -97,10 +120,11 @@ class CostVolumeCW:
             self.V = nghbr_feat.shape[0] // self.B
             self.ref_cl = lib.pack_features(ref_feat.detach().float().contiguous(), self.fe, pad=0)
             self.src_pad = lib.pack_features(nghbr_feat.detach().float().contiguous(), self.fe, pad=1)
-        g = nghbr_gmms.detach().float().contiguous()
-        self.src_gmm_pad = lib.pack_gmm(g)
-        # the production matcher for D > 32 reads the (mu, sigma) map per quad origin in quad form (3 fma per bilinear sample)
-        self.src_gmm_quad = lib.pack_gmm_quad(g) if (path & 0xff) in (0, 4) else None
+        # the source (mu, sigma) maps are packed on first use, in the layout the selected kernel reads: the production matcher
+        # for D > 32 takes the quad form (3 fma per bilinear sample), every other kernel the interleaved zero-bordered map
+        self._gmm_nchw = nghbr_gmms.detach().float().contiguous()
+        self._gmm_pad = None
+        self._gmm_quad = None
         self.poses = nghbr_poses.detach().to(device=dev, dtype=torch.float32).contiguous()
         self.is_valid = _valid_to_device(is_valid, dev)
         self.intM = _to_device_cached(cam_intrins["intM"], dev, torch.float32, _INTRINS_CACHE)
@@ -125,10 +149,27 @@ class CostVolumeCW:
         if sink is not None:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        res = lib.cost_volume_cw(self.ref_cl, self.src_pad, self.src_gmm_pad, self.poses, self.is_valid,
-                                 self.intM, self.rays, self.kappa, ref_gmm=ref_gmm, k_list=k_list,
-                                 d_volume=d_volume, out=out, path=self.path, stats=stats, out_split=out_split,
-                                 gate_bits=gate_bits, ray_params=self.ray_params, src_gmm_quad=self.src_gmm_quad)
+        D = d_volume.shape[1] if d_volume is not None else len(k_list)
+        quad = (self.path & 0xff) in (0, 4) and D > 32 and d_volume is None and stats is None
+        if quad and self._gmm_quad is None:
+            self._gmm_quad = lib.pack_gmm_quad(self._gmm_nchw)
+        if not quad and self._gmm_pad is None:
+            self._gmm_pad = lib.pack_gmm(self._gmm_nchw)
+
+        def launch():
+            return lib.cost_volume_cw(self.ref_cl, self.src_pad, self._gmm_pad, self.poses, self.is_valid,
+                                      self.intM, self.rays, self.kappa, ref_gmm=ref_gmm, k_list=k_list,
+                                      d_volume=d_volume, out=out, path=self.path, stats=stats, out_split=out_split,
+                                      gate_bits=gate_bits, ray_params=self.ray_params, src_gmm_quad=self._gmm_quad if quad else None)
+        try:
+            res = launch()
+        except lib.MagnetError as e:
+            # the one condition handled here: the kernel that reads the quad form declined the shape and the interleaved map was
+            # not packed yet (the library says so with MAGNET_E_SHAPE); everything else propagates
+            if not (e.code == lib.E_SHAPE and quad and self._gmm_pad is None and (self.path & 0xff) in (0, 4)):
+                raise
+            self._gmm_pad = lib.pack_gmm(self._gmm_nchw)
+            res = launch()
         if sink is not None:
             e1.record()
             sink.append((e0, e1))

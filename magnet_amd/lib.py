@@ -200,8 +200,10 @@ def cost_volume_cw(ref_feat_cl, src_feat_pad, src_gmm_pad, poses, is_valid, intM
     a.feat_dtype = fe
     a.ref_feat_cl, a.src_feat_pad = r.data_ptr(), s.data_ptr()
     a.mode = int(mode)
-    if mode == 1 and src_gmm_pad is None:
-        g = s                                                      # no (mu,sigma) maps in est_costvolume_F mode
+    if src_gmm_pad is None:
+        if mode != 1 and src_gmm_quad is None:
+            raise MagnetError("need src_gmm_pad (pack_gmm) or src_gmm_quad (pack_gmm_quad)")
+        g = s                                                      # est_costvolume_F mode has no (mu,sigma) maps; or only the quad form is given
     else:
         g = _dev(src_gmm_pad, "src_gmm_pad", torch.float32)
         if tuple(g.shape) != (V * B, h + 2, w + 2, 2):

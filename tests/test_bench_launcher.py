@@ -27,6 +27,29 @@ def test_bench_spawns_two_ranks_dry_run():
     assert d["weight_broadcast_bytes"] == (9 * (256 + 64) * 128 + 128 + 2 * (128 * 128 + 128) + 2 * 128 + 2) * 4   # G-Net at D=64
 
 
+def test_bench_reports_per_rank_rates():
+    d = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--frames", "4"])
+    assert len(d["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in d["per_rank_frames_per_s"])
+
+
+def test_dead_rank_takes_the_launch_down_quickly():
+    """One rank exits with 3 before the rendezvous: the launcher must stop the surviving rank (which is waiting for the
+    group) and return non-zero within seconds — not after a collective timeout."""
+    import time
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e["MAGNET_BENCH_FAIL_RANK"] = "1"
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2"],
+                         env=e, capture_output=True, text=True, timeout=60)
+    dt = time.monotonic() - t0
+    assert out.returncode == 3, (out.returncode, out.stderr[-1500:])
+    assert dt < 10.0 + 8.0, f"launcher took {dt:.1f} s to give up"          # the bound is 10 s; python + torch start-up of the ranks comes on top
+    assert "[bench launcher] rank 1 exited with 3" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]      # no result line from a failed launch
+
+
 def test_bench_single_rank_dry_run_needs_no_group():
     d = _run(["--gpus", "1", "--dry-run", "--steps", "2"])
     assert d["n_gpus"] == 1 and d["weight_broadcast_bytes"] == 0
