@@ -265,6 +265,11 @@ def main():
     ap.add_argument("--overlap-pack", action="store_true", help="x_d3 repack on a side stream beside the matcher (measured: no gain)")
     ap.add_argument("--sustain-s", type=float, default=6.0, help="extra untimed-by-contract run of this many seconds after the K "
                     "steps, reported as sustained_frames_per_s (0 = skip)")
+    ap.add_argument("--with-fnet", action="store_true", help="the step starts from the IMAGES: F-Net (matrix-core path, magnet_amd/fnet.py) on the "
+                    "1 + V images of every reference frame, then the loop; D-Net outputs stay resident synthetic tensors (torch.hub "
+                    "backbone, not buildable offline).  Reported beside the contract line, never instead of it")
+    ap.add_argument("--dev-lib", action="store_true", help="tools/ only: bind to libmagnet_hip_dev.so (python -m magnet_amd.build --dev), "
+                    "the build that honours the MAGNET_* variant switches; never a valid result line")
     ap.add_argument("--dry-run", action="store_true", help="launcher / distributed self-test without a GPU: gloo backend, "
                     "the step is a no-op (used by tests/test_bench_launcher.py)")
     a = ap.parse_args()
@@ -287,8 +292,10 @@ def main():
     torch.cuda.set_device(device)
 
     from magnet_amd import build as mbuild, lib
+    if a.dev_lib:
+        lib.use_dev_build()
     if rank == 0:
-        mbuild.build()
+        mbuild.build(dev=a.dev_lib)
     mdist.barrier()
     lib.load()
     from magnet_amd.homography import CostVolumeCW
@@ -298,7 +305,7 @@ def main():
     iters = a.iters or wl.iters
     fdt = a.feat_dtype or wl.feat_dtype
     # enough frames per step that one launch fills the chip and the working set exceeds the 256 MiB L3
-    B = a.frames or max(1, min(64, int(round(1200e6 / max(wl.algorithmic_bytes(), 1)))))
+    B = a.frames or max(1, min(16 if a.with_fnet else 64, int(round(1200e6 / max(wl.algorithmic_bytes(), 1)))))
     torch.manual_seed(1234)                               # every rank draws its own init; rank 0's wins below
     model = MAGNET(make_args(wl, iters), d_net=_NoBackbone(), f_net=_NoBackbone(), feat_dtype=fdt,
                    conv_backend=a.conv_backend)
@@ -319,7 +326,31 @@ def main():
     from magnet_amd.convnet import ConvStackMFMA
 
     model.matcher_path = a.path
-    if a.kernel_only:
+    if a.with_fnet:
+        from magnet_amd import fnet as mfnet
+
+        class _ResidentDNet(torch.nn.Module):                # D-Net outputs ((mu, sigma) maps, x_d3) as resident tensors
+            def __init__(self, gmms, x_d3):
+                super().__init__(); self.gmms, self.x_d3 = gmms, x_d3
+
+            def forward(self, img):
+                return self.gmms, self.x_d3
+        fa = make_args(wl, iters); fa.FNET_architecture = "PSM-Net"
+        model.f_net = mfnet.FNET(fa).to(device).eval()
+        mdist.broadcast_module_(model.f_net, src=0)
+        model.d_net = _ResidentDNet(torch.cat([inp["ref_gmms"], inp["nghbr_gmms"]], dim=0),
+                                    inp["x_d3"])          # the forward keeps x_d3[:B] only (MAGNET.py:139)
+        model.fnet_mfma = True
+        gi = torch.Generator(device=device).manual_seed(77 + rank)
+        ref_img = torch.randn(B, 3, 4 * wl.h, 4 * wl.w, generator=gi, device=device)
+        nb_img = torch.randn(wl.V * B, 3, 4 * wl.h, 4 * wl.w, generator=gi, device=device)
+
+        def step(timed):
+            CostVolumeCW.event_sink = ev_pairs if timed else None
+            ConvStackMFMA.event_sink = conv_events if timed else None
+            with torch.no_grad():
+                model(ref_img, nb_img, inp["nghbr_poses"], inp["is_valid"], inp["cam_intrins"], mode="test")
+    elif a.kernel_only:
         matcher = CostVolumeCW(inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"],
                                inp["is_valid"], inp["cam_intrins"], 5, feat_dtype=fdt, path=a.path)
         if a.nchw_out:
@@ -392,7 +423,7 @@ def main():
     # the same step when the backbones hand their outputs over in the kernels' layouts (what magnet_amd/fnet.py's F-Net does):
     # no pack pass.  Reported next to the contract number, never instead of it.
     packed_ms = None
-    if not (a.kernel_only or a.graph or a.packed_inputs) and a.conv_backend == "mfma":
+    if not (a.kernel_only or a.graph or a.packed_inputs or a.with_fnet) and a.conv_backend == "mfma":
         packed = (lib.pack_features(inp["ref_feat"], lib.feat_enum(fdt), pad=0), lib.pack_features(inp["nghbr_feat"], lib.feat_enum(fdt), pad=1))
         gh, gl, ctot, coff = model.gnet_input_buffer(B, wl.h, wl.w, device)
         lib.pack_split(inp["x_d3"], gh, gl, ctot, coff)
@@ -439,9 +470,12 @@ def main():
             "config": {"workload": workload_desc,
                        "feature_storage": fdt, "arithmetic": "fp32 (matcher: fp32 view accumulation, tolerance-parity geometry; convolutions "
                                                              "bf16x3-split on the matrix cores with fp32 accumulation)",
-                       "inputs": ("backbone outputs in the kernels' layouts (no pack pass)" if a.packed_inputs else
+                       "inputs": (f"{1 + wl.V} images of {4 * wl.h}x{4 * wl.w} per reference frame; F-Net (PSMNet, matrix-core path) INSIDE the step, D-Net "
+                                  "outputs resident" if a.with_fnet else
+                                  "backbone outputs in the kernels' layouts (no pack pass)" if a.packed_inputs else
                                   "backbone outputs as the reference's NCHW fp32 tensors (pack passes inside the step)"),
                        "frames_per_gpu_per_step": B, "step": "kernel-only" if a.kernel_only else
+                       ("F-Net on every image + " if a.with_fnet else "") +
                        ("pack + I x (fused cost volume + G-Net + Gaussian update) + mask head + convex upsample; convs on "
                         + ("the bf16x3 MFMA kernel" if a.conv_backend == "mfma" else "MIOpen fp32")),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; "

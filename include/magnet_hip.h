@@ -302,14 +302,15 @@ MAGNET_API int magnet_upsample_depth_cl_n(const float *depths, const float *mask
                                           int32_t B, int32_t h, int32_t w, void *stream);
 
 /* Depth-error reductions on the device (utils.compute_depth_errors, utils/utils.py:106-144, with the masking /
- * clamping of test_MaGNet.py:43,58-79): pred (B,2,H*W) [mu, sigma], gt (B,H*W).  sums: OUT double (B,16), zeroed by
- * the call: n, sum|d|, sum|d|/gt, sum d^2/gt, sum d^2, sum(ln gt-ln p)^2, sum(ln p-ln gt), sum|log10 gt-log10 p|,
+ * clamping of test_MaGNet.py:43,58-79): pred (B,2,H*W) [mu, sigma], gt (B,H*W).  sums: OUT double (B,16), every
+ * element written by the call (no memset needed): n, sum|d|, sum|d|/gt, sum d^2/gt, sum d^2, sum(ln gt-ln p)^2, sum(ln p-ln gt), sum|log10 gt-log10 p|,
  * sum(1/gt-1/p)^2, #(t<1.25), #(t<1.25^2), #(t<1.25^3), sum nll, 0,0,0.  The 12 metrics are ratios of these
  * (magnet_amd/metrics.py). */
 MAGNET_API int magnet_depth_metrics(const float *pred, const float *gt, double *sums, int32_t B, int32_t HW,
                                     float min_depth, float max_depth, void *stream);
 /* The same over the evaluation window rows [y0,y1) x columns [x0,x1) only: the reference's garg / eigen crops for KITTI
- * (test_MaGNet.py:63-71).  Both entry points sum in a fixed order (one workgroup per frame): results are deterministic. */
+ * (test_MaGNet.py:63-71).  Both entry points sum in a fixed order (64 workgroups per frame
+ * writing partial sums to a stream-ordered scratch allocation, then one fixed-order final sum): deterministic, no atomics. */
 MAGNET_API int magnet_depth_metrics_crop(const float *pred, const float *gt, double *sums, int32_t B, int32_t H, int32_t W,
                                          float min_depth, float max_depth, int32_t y0, int32_t y1, int32_t x0, int32_t x1,
                                          void *stream);

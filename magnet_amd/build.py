@@ -1,6 +1,6 @@
 """Build libmagnet_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m magnet_amd.build [--force]
+    python -m magnet_amd.build [--force] [--dev]
 
 Flags that matter: -ffp-contract=off (the kernels mirror the reference's separately-rounded
 multiply/add; fused operations are written as explicit fmaf), correctly-rounded fp32 divide
@@ -14,6 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmagnet_hip.so")
+DEV_LIB = os.path.join(HERE, "libmagnet_hip_dev.so")      # -DMAGNET_DEV build, loaded only by tools/ (lib.use_dev_build())
 SOURCES = ["api.hip", "cost_volume.hip", "cost_volume_worklist.hip", "cost_volume_cand.hip", "cost_volume_fast.hip", "cost_volume_fast64.hip", "cost_volume_v3.hip", "cost_volume_f_bwd.hip", "cost_volume_f_gather.hip", "conv_mfma.hip", "fnet_kernels.hip", "elementwise.hip"]
 HEADERS = ["cv_common.hpp", "cv_fast_common.hpp", "cv_runs.hpp", "conv_common.hpp", "warp_math.hpp", os.path.join("..", "..", "include", "magnet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -28,10 +29,10 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -44,17 +45,16 @@ EXTRA_FLAGS = {"cost_volume_fast.hip": ["-fno-slp-vectorize"], "cost_volume_fast
 
 
 def build(force: bool = False, verbose: bool = False, dev: bool | None = None) -> str:
-    """dev=True (or MAGNET_DEV=1 in the environment): compile with -DMAGNET_DEV, which makes the library honour
+    """dev=True: a SECOND library, libmagnet_hip_dev.so, compiled with -DMAGNET_DEV: it honours
     MagnetCostVolumeArgs.dev_flags and the MAGNET_* environment switches of tools/ (kernel variants, timing ablations).
-    The product build ignores all of them."""
-    if dev is None:
-        dev = os.environ.get("MAGNET_DEV", "") not in ("", "0")
-    if not force and not _stale() and not dev:
-        return LIB
+    The product library ignores all of them and is never replaced by this build; only tools/ load the dev library."""
+    dev = bool(dev)
+    if not force and not _stale(DEV_LIB if dev else LIB):
+        return DEV_LIB if dev else LIB
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        o = os.path.join(CSRC, s.replace(".hip", ".dev.o" if dev else ".o"))
         cmd = [hipcc(), *FLAGS, *(["-DMAGNET_DEV"] if dev else []), *EXTRA_FLAGS.get(s, []), "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
@@ -66,10 +66,10 @@ def build(force: bool = False, verbose: bool = False, dev: bool | None = None) -
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
-    subprocess.check_call(cmd)
-    return LIB
+    out = DEV_LIB if dev else LIB
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv or "--dev" in sys.argv, verbose=True, dev=True if "--dev" in sys.argv else None))
+    print(build(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))

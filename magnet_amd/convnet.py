@@ -115,45 +115,48 @@ class ConvStackMFMA:
         return out
 
     @torch.no_grad()
-    def packed_first_split(self, device, n_var):
+    def packed_first_split(self, device, n_var, inv_off):
         """First layer split by input channels of the (padded) input buffer: channels [0, n_var) vary per refinement
-        iteration (the cost volume), the rest is loop-invariant (x_d3).  Returns (variable part, invariant part):
-        variable = weights over buffer channels [0, round_up(n_var,32)) with the invariant positions zeroed (+ bias, ReLU);
-        invariant = weights over ALL buffer channels with the variable positions zeroed (no bias, no ReLU)."""
+        iteration (the cost volume), channels [inv_off, cin_pad) are loop-invariant (x_d3), everything between is padding.
+        Returns (variable part, invariant part): variable = weights over buffer channels [0, round_up(n_var,32)) (+ bias,
+        ReLU); invariant = weights over buffer channels [inv_off, cin_pad) only — its launch reads the buffer at a channel
+        offset, so no MFMA work is spent on the cost channels' zero weights (no bias, no ReLU)."""
         pk = self.packed(device)[0]
-        key = ("split", n_var, self._key)
+        key = ("split", n_var, inv_off, self._key)
         if getattr(self, "_split_key", None) == key:
             return self._split
+        if inv_off % 32 or inv_off < n_var:
+            raise lib.MagnetError("packed_first_split: the invariant channels must start at a multiple of 32 behind the variable ones")
         w = (pk["w_hi"].float() + pk["w_lo"].float())                       # exact: hi + lo is how the kernel sees them
         cv = _round_up(n_var, 32)
         wv = w[:, :, :cv].clone(); wv[:, :, n_var:] = 0
-        wi = w.clone(); wi[:, :, :n_var] = 0
-        # split each part again from the ORIGINAL fp32 weights would be more accurate than re-splitting hi+lo, but
-        # hi+lo already carries 16 mantissa bits and re-splitting it is exact (hi, lo are recovered bit for bit)
+        wi = w[:, :, inv_off:].clone()
+        # re-splitting hi + lo is exact (16 mantissa bits): hi, lo are recovered bit for bit
         vh, vl = split_bf16(wv.contiguous()); ih, il = split_bf16(wi.contiguous())
         var = dict(w_hi=vh, w_lo=vl, bias=pk["bias"], taps=pk["taps"], cin=cv, cout_pad=pk["cout_pad"], relu=pk["relu"])
-        inv = dict(w_hi=ih, w_lo=il, bias=torch.zeros_like(pk["bias"]), taps=pk["taps"], cin=pk["cin"],
+        inv = dict(w_hi=ih, w_lo=il, bias=torch.zeros_like(pk["bias"]), taps=pk["taps"], cin=pk["cin"] - inv_off,
                    cout_pad=pk["cout_pad"], relu=False)
         self._split_key, self._split = key, (var, inv)
         return self._split
 
-    def run_invariant(self, in_hi, in_lo, in_ld, rows, wp, work, n_var):
-        """Loop-invariant partial sums of the first layer: fp32 (rows, cout_pad), computed once per forward."""
-        _, inv = self.packed_first_split(in_hi.device, n_var)
+    def run_invariant(self, in_hi, in_lo, in_ld, rows, wp, work, n_var, inv_off):
+        """Loop-invariant partial sums of the first layer: fp32 (rows, cout_pad), computed once per forward.  in_hi / in_lo:
+        channel 0 of the buffer; the launch starts at channel inv_off."""
+        _, inv = self.packed_first_split(in_hi.device, n_var, inv_off)
         key = ("partial", rows, inv["cout_pad"])
         if key not in work:
             work[key] = torch.empty((rows, inv["cout_pad"]), dtype=torch.float32, device=in_hi.device)
-        lib.conv_mfma(in_hi, in_lo, in_ld, inv["cin"], inv["w_hi"], inv["w_lo"], inv["bias"], inv["taps"], wp, False, rows,
-                      out_f32=work[key])
+        lib.conv_mfma(in_hi[:, inv_off:], in_lo[:, inv_off:], in_ld, inv["cin"], inv["w_hi"], inv["w_lo"], inv["bias"], inv["taps"], wp,
+                      False, rows, out_f32=work[key])
         return work[key]
 
-    def run(self, in_hi, in_lo, in_ld, rows, wp, work, first_addend=None, n_var=None):
+    def run(self, in_hi, in_lo, in_ld, rows, wp, work, first_addend=None, n_var=None, inv_off=None):
         """in_hi/in_lo: bf16 views whose data_ptr is row 0, channel 0 of this stack's input; `work`: dict for cached
         hidden buffers.  Returns (fp32 tensor (rows, cout_pad_last), cout_pad_last)."""
         packs = self.packed(in_hi.device)
         if first_addend is not None:
             # first layer over the per-iteration channels only; the invariant part arrives as `first_addend`
-            packs = [self.packed_first_split(in_hi.device, n_var)[0]] + list(packs[1:])
+            packs = [self.packed_first_split(in_hi.device, n_var, inv_off)[0]] + list(packs[1:])
         cur_hi, cur_lo, cur_ld = in_hi, in_lo, in_ld
         if self._chain is not None and self.fuse_epilogue:
             pk, ch = packs[0], self._chain

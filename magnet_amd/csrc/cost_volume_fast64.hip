@@ -185,8 +185,9 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
                         const float ax = 1.0f - bx, ay = 1.0f - by;
                         wnw[u] = ax * ay; wne[u] = bx * ay; wsw[u] = ax * by; wse[u] = bx * by;   // homography.py:150-152
                         inwin[u] = (__float_as_uint(ixs) < xlim) && (__float_as_uint(iys) < ylim);
-                        // v_cvt_u32_f32 saturates: negative / NaN -> 0; then an unsigned min against the map size
-                        const uint32_t xq = min((uint32_t)x0f, (uint32_t)p.w), yq = min((uint32_t)y0f, (uint32_t)p.h);
+                        // clamp in float first (v_med3_f32; NaN -> 0): the float -> unsigned conversion is then defined
+                        const uint32_t xq = (uint32_t)__builtin_amdgcn_fmed3f(x0f, 0.0f, (float)p.w);
+                        const uint32_t yq = (uint32_t)__builtin_amdgcn_fmed3f(y0f, 0.0f, (float)p.h);
                         qi[u] = __umul24(yq, (uint32_t)Wp) + xq;                 // quad origin in the padded map (exact when inwin)
                         const unsigned char* __restrict__ sgm = sgm_b + (size_t)vv * sgm_vstride;
                         if (!LEAD) {

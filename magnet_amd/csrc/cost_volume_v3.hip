@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     constexpr bool SPLIT = (OPT & 64) != 0;               // the split-bf16 channel-last output form only (cost_hi given): no NCHW staging code, fewer live scalars
     constexpr int NPX = V3_NPX;
     constexpr int IPP = 64 / (4 * LPU);                   // items per correlation pass
+    constexpr bool QF = LPU == 4;                         // an item's four taps share a 16-lane row: correlations stored in quad form (cv_runs.hpp)
     constexpr int NPASS = ((OPT >> 8) & 15) ? ((OPT >> 8) & 15) : V3_NPASS_DEFAULT;   // passes fetched together
     constexpr int CSTR = LPU * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -133,7 +134,6 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     fwave_lds_fence();
 
     const uint32_t xlim = __float_as_uint((float)(p.w + 1)), ylim = __float_as_uint((float)(p.h + 1));   // see cost_volume_fast.hip
-    const float Wpf = (float)Wp;
     const int sub = lane & (LPU - 1), tap = (lane / LPU) & 3, upair = lane / (4 * LPU);          // correlation roles
     const uint32_t lane_src_off = (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes + (uint32_t)sub * 16u;
     const uint32_t tap4 = (uint32_t)tap * 4u;
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
 #pragma unroll
                         for (int cc = 0; cc < CPL; ++cc) part = fdot_chunk(rvp[cc], sv[a][cc], part, FeatT());
                         part = LPU == 8 ? freduce8(part) : v3_reduce4(part);
+                        if (QF) part = v3_quadform16(part);                                 // slot = {c00, dc/dx, dc/dy, d2c/dxdy}
                         if (sub == 0) v3_st_f1(ent[a].y + tap4, part);                     // pad units write the dump slot
                     }
                 }
@@ -231,13 +232,13 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
                     const float rz = __builtin_amdgcn_rcpf(Pz);                           // homography.py:133
                     const float ixs = __builtin_fmaf(Px, rz, 0.5f);
                     const float iys = __builtin_fmaf(Py, rz, 0.5f);
-                    const float x0f = __builtin_floorf(ixs), y0f = __builtin_floorf(iys);
-                    bx[u] = ixs - x0f; by[u] = iys - y0f;
+                    bx[u] = __builtin_amdgcn_fractf(ixs); by[u] = __builtin_amdgcn_fractf(iys);     // = ixs - floor(ixs), exact inside the window
                     fxy[u] = bx[u] * by[u];
                     const unsigned long long wx = __builtin_amdgcn_ballot_w64(__float_as_uint(ixs) < xlim);
                     const unsigned long long wy = __builtin_amdgcn_ballot_w64(__float_as_uint(iys) < ylim);
                     Wb[u] = (u < nact) ? (wx & wy) : 0ull;
-                    keyf[u] = (uint32_t)__builtin_fmaf(y0f, Wpf, x0f) + vt.x;            // quad index relative to (frame b, view 0); garbage outside the window
+                    // quad index relative to (frame b, view 0): truncation = floor inside the window (ixs, iys >= 0); garbage outside it
+                    keyf[u] = __umul24(v3_cvt_u32_sat(iys), (uint32_t)Wp) + v3_cvt_u32_sat(ixs) + vt.x;
                     const unsigned char* gp = gq_b + (min(keyf[u], kmax) << 5);          // clamped: every lane loads valid memory
                     q0[u] = *reinterpret_cast<const float4*>(gp);
                     q1[u] = *reinterpret_cast<const float4*>(gp + 16);
@@ -269,12 +270,17 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
 #pragma unroll
                 for (int u = 0; u < VG; ++u) {
                     const float4 c4 = v3_ld_f4(raddr[u]);
-                    const float w10 = bx[u] - fxy[u], w01 = by[u] - fxy[u];
-                    const float w00 = (1.0f - bx[u]) - w01;
-                    float c = c4.x * w00;                                                  // homography.py:150,155
-                    c = __builtin_fmaf(c4.y, w10, c);
-                    c = __builtin_fmaf(c4.z, w01, c);
-                    c = __builtin_fmaf(c4.w, fxy[u], c);
+                    float c;
+                    if (QF) {                                                              // homography.py:150,155 (grid_sample's bilinear weights, factored)
+                        c = __builtin_fmaf(fxy[u], c4.w, __builtin_fmaf(by[u], c4.z, __builtin_fmaf(bx[u], c4.y, c4.x)));
+                    } else {
+                        const float w10 = bx[u] - fxy[u], w01 = by[u] - fxy[u];
+                        const float w00 = (1.0f - bx[u]) - w01;
+                        c = c4.x * w00;
+                        c = __builtin_fmaf(c4.y, w10, c);
+                        c = __builtin_fmaf(c4.z, w01, c);
+                        c = __builtin_fmaf(c4.w, fxy[u], c);
+                    }
                     acc += v3_sel_f(Gb[u], c, 0.f);                                        // homography.py:159,116 (fp32 here)
                 }
                 fwave_lds_fence();
@@ -330,7 +336,13 @@ static hipError_t launch_v3_v(const CvParams& p0, hipStream_t stream) {
     const uint64_t nt = (uint64_t)p.tiles_x * p.tiles_y;
     p.magic_tiles = nt > 1 ? (uint32_t)((((uint64_t)1 << 32) + nt - 1) / nt) : 0u;
     p.magic_tiles_x = p.tiles_x > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)p.tiles_x - 1) / (uint64_t)p.tiles_x) : 0u;
-    const size_t lds = v3_lds_bytes(p, VG);
+    size_t lds = v3_lds_bytes(p, VG);
+#ifdef MAGNET_DEV
+    {   // dev: cap the workgroups per CU (waves per SIMD) by asking for more LDS than the kernel uses
+        const int cap = (p.ablate & 0x300000) == 0x300000 ? 3 : (p.ablate & 0x200000) ? 4 : (p.ablate & 0x100000) ? 5 : 0;
+        if (cap) { const size_t need = (size_t)160 * 1024 / (cap + 1) + 512; if (lds < need) lds = need; }
+    }
+#endif
     constexpr int NP = V3_NPASS_DEFAULT << 8;
     constexpr int MW2 = MINW > 5 ? 5 : MINW;             // the NCHW-output and gate-bit instances carry more live values: one wave per SIMD less instead of scratch
 #ifdef MAGNET_DEV
@@ -347,10 +359,11 @@ static hipError_t launch_v3_v(const CvParams& p0, hipStream_t stream) {
 
 template <typename FeatT, int CPL, bool FULL, int MINW, int LPU>
 static hipError_t launch_v3(const CvParams& p, hipStream_t stream) {
-    int vg = p.V >= 4 ? 4 : p.V;
-    if (p.V > 4 && p.V % 4 != 0 && (p.V % 3 == 0 || p.V % 4 < p.V % 3)) vg = 3;
+    // views in flight per pixel.  Two: 68 registers = 7 waves per SIMD; four views cost 78 registers = 6 waves and lose 3 % both
+    // alone (0.906 vs 0.879 ms per 64 C2 frames, warm) and inside the step; one view (8 waves) has too little to overlap: 0.975
+    int vg = p.V == 1 ? 1 : (p.V % 2 == 0 ? 2 : (p.V % 3 == 0 ? 3 : 2));
 #ifdef MAGNET_DEV
-    if (p.ablate & 0x400000) vg = 2;                                                     // dev: views per group
+    if (p.ablate & 0x400000) vg = 4;                                                     // dev: views per group
     if (p.ablate & 0x800000) vg = 1;
 #endif
     switch (vg) {
@@ -380,6 +393,7 @@ hipError_t launch_cv_v3(const CvParams& p, hipStream_t stream, bool* handled) {
 #ifdef MAGNET_DEV
         if (nchunk == 8 && (p.ablate & 0x1000)) return launch_v3<uint16_t, 2, true, 8, 4>(p, stream);    // dev: occupancy A/B
         if (nchunk == 8 && (p.ablate & 0x2000)) return launch_v3<uint16_t, 2, true, 4, 4>(p, stream);
+        if (nchunk == 8 && (p.ablate & 0x10000)) return launch_v3<uint16_t, 2, true, 7, 4>(p, stream);
 #endif
         if (nchunk == 8)  return launch_v3<uint16_t, 2, true, 6, 4>(p, stream);          // F = 64: 4 lanes x 32 B per (item, tap) unit
         if (nchunk <= 8)  return launch_v3<uint16_t, 1, false, 6, 8>(p, stream);

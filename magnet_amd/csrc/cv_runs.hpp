@@ -25,6 +25,13 @@ __device__ __forceinline__ void v3_st_f1(uint32_t a, float v) { V3_LDS(float, a)
 // Masked stores take the lane mask as a 64-bit SCALAR operand (no per-lane predicate has to be materialised): v3_st1_mask / v3_st2_mask below.
 
 // select by a 64-bit scalar lane mask (bit set -> t)
+// float -> uint32 with the hardware's saturation (v_cvt_u32_f32: negative / NaN -> 0, >= 2^32 -> 0xffffffff).  A C cast of an
+// out-of-range float is undefined; the projected coordinate of an out-of-window candidate can be anything.
+__device__ __forceinline__ uint32_t v3_cvt_u32_sat(float x) {
+    uint32_t r;
+    asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ __forceinline__ float v3_sel_f(uint64_t mask, float t, float f) {
     float r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(mask));
@@ -44,6 +51,17 @@ __device__ __forceinline__ float v3_reduce4(float v) {
     asm volatile("s_nop 3\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(v));   // (the producer is a v_dot2c: hipcc itself leaves 3 wait states)
     asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(t));
     return r;
+}
+
+// The four tap correlations of an item sit in four consecutive 4-lane banks of one 16-lane row (c00, c10, c01, c11).  Turn them
+// into the quad form {c00, c10 - c00, c01 - c00, (c11 - c01) - (c10 - c00)} in place with two bank-masked DPP subtractions (a
+// bank the mask leaves out keeps its value), so that the bilinear combine of a candidate is three fma instead of four weights
+// and four multiply-adds: c = c00 + bx * dx + by * dy + (bx * by) * dxy.
+__device__ __forceinline__ float v3_quadform16(float x) {
+    asm volatile("s_nop 1\n\tv_subrev_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"      // banks 1, 3: x -= x[lane - 4]
+                 "s_nop 1\n\tv_subrev_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc"            // banks 2, 3: x -= x[lane - 8]
+                 : "+v"(x));
+    return x;
 }
 
 // Leaders (first lanes of runs, ballot L) whose run holds at least one open gate (ballot G; every G lane belongs to a run).

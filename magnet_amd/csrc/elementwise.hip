@@ -294,24 +294,27 @@ hipError_t launch_upsample_cl(const float* d, const float* m, int ld, float* o, 
 
 // ---- depth metrics (utils.compute_depth_errors, utils/utils.py:106-144 + the masking of test_MaGNet.py:43,58-79) ----
 // Per frame: sums over valid pixels (min < gt < max) of the terms each metric averages; fp64 accumulation
-// (thread -> wave DPP-free shuffle -> block LDS -> one atomicAdd per block and term).
+// (thread -> wave shuffle tree -> workgroup LDS -> per-workgroup partials -> fixed-order final sum; no atomics).
 // sums[b][0..15] = n, |d|, |d|/gt, d^2/gt, d^2, (ln gt - ln p)^2, (ln p - ln gt), |log10 gt - log10 p|,
 //                  (1/gt - 1/p)^2, [t<1.25], [t<1.25^2], [t<1.25^3], nll term, 0, 0, 0      with d = gt - p, t = max(gt/p, p/gt)
 constexpr int MET_N = 16;
-// One workgroup of 1024 threads per frame, fixed summation order (per-thread strided sums -> wave shuffle tree -> 16 wave
-// partials added in order): results are run-to-run deterministic, no atomics, no memset.  Optional evaluation window
-// [cy0,cy1) x [cx0,cx1) = the reference's rectangular garg / eigen crops (test_MaGNet.py:63-71); cy1 < 0 = whole frame.
-__global__ __launch_bounds__(1024) void depth_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
-                                                              double* __restrict__ sums, int HW, int W, float dmin, float dmax,
-                                                              int cy0, int cy1, int cx0, int cx1) {
-    const int b = blockIdx.x;
+constexpr int MET_PARTS = 64;      // workgroups per frame in the first stage (fixed: the summation order never depends on the launch)
+// Two stages, both in a fixed order, so results are run-to-run deterministic without atomics: stage 1 = MET_PARTS workgroups
+// of 256 threads per frame, each over a fixed interleaved slice of the frame (per-thread strided sums -> wave shuffle tree
+// -> 4 wave partials added in order) writing 13 partial sums; stage 2 = one wave per frame adding the MET_PARTS partials in
+// index order.  Optional evaluation window [cy0,cy1) x [cx0,cx1) = the reference's rectangular garg / eigen crops
+// (test_MaGNet.py:63-71); cy1 < 0 = whole frame.
+__global__ __launch_bounds__(256) void depth_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                             double* __restrict__ part, int HW, int W, float dmin, float dmax,
+                                                             int cy0, int cy1, int cx0, int cx1) {
+    const int b = blockIdx.y;
     double acc[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) acc[i] = 0.0;
     const float* mu = pred + (size_t)b * 2 * HW;
     const float* sg = mu + HW;
     const float* g = gt + (size_t)b * HW;
-    for (int i = threadIdx.x; i < HW; i += 1024) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += MET_PARTS * 256) {
         float gv = g[i];
         if (gv > dmax) gv = 0.f;                                       // test_MaGNet.py:43
         if (!(gv > dmin && gv < dmax)) continue;                       // test_MaGNet.py:58
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(1024) void depth_metrics_kernel(const float* __rest
         acc[9] += (t < 1.25) ? 1.0 : 0.0; acc[10] += (t < 1.25 * 1.25) ? 1.0 : 0.0; acc[11] += (t < 1.25 * 1.25 * 1.25) ? 1.0 : 0.0;
         acc[12] += 0.5 * (log(var) + 1.8378770664093453 + d * d / var);    // ln(2 pi)
     }
-    __shared__ double red[16][13];
+    __shared__ double red[4][13];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
@@ -343,18 +346,33 @@ __global__ __launch_bounds__(1024) void depth_metrics_kernel(const float* __rest
         if (lane == 0) red[wv][k] = v;
     }
     __syncthreads();
-    if (threadIdx.x < MET_N) {
-        double v = 0.0;
-        if (threadIdx.x < 13)
-            for (int w2 = 0; w2 < 16; ++w2) v += red[w2][threadIdx.x];
-        sums[(size_t)b * MET_N + threadIdx.x] = v;
-    }
+    if (threadIdx.x < 13)
+        part[((size_t)b * MET_PARTS + blockIdx.x) * 13 + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+__global__ __launch_bounds__(64) void depth_metrics_final_kernel(const double* __restrict__ part, double* __restrict__ sums) {
+    const int b = blockIdx.x, k = threadIdx.x;
+    if (k >= MET_N) return;
+    double v = 0.0;
+    if (k < 13)
+        for (int q = 0; q < MET_PARTS; ++q) v += part[((size_t)b * MET_PARTS + q) * 13 + k];
+    sums[(size_t)b * MET_N + k] = v;
+}
+
+// the partial sums live in a stream-ordered allocation (hipMallocAsync / hipFreeAsync): no state kept between calls, safe
+// with concurrent calls on different streams
 hipError_t launch_depth_metrics(const float* pred, const float* gt, double* sums, int B, int HW, int W, float dmin, float dmax,
                                 int cy0, int cy1, int cx0, int cx1, hipStream_t s) {
-    hipLaunchKernelGGL(depth_metrics_kernel, dim3((unsigned)B), dim3(1024), 0, s, pred, gt, sums, HW, W, dmin, dmax, cy0, cy1, cx0, cx1);
-    return hipGetLastError();
+    double* part = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&part), (size_t)B * MET_PARTS * 13 * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(depth_metrics_kernel, dim3(MET_PARTS, (unsigned)B), dim3(256), 0, s, pred, gt, part, HW, W, dmin, dmax,
+                       cy0, cy1, cx0, cx1);
+    hipLaunchKernelGGL(depth_metrics_final_kernel, dim3((unsigned)B), dim3(64), 0, s, part, sums);
+    e = hipGetLastError();
+    const hipError_t e2 = hipFreeAsync(part, s);
+    return e != hipSuccess ? e : e2;
 }
 
 // ---- learned convex upsampling -------------------------------------------------------------------

@@ -64,6 +64,15 @@ class MagnetCostVolumeArgs(ctypes.Structure):
 _lib = None
 
 
+def use_dev_build():
+    """tools/ only: bind to libmagnet_hip_dev.so (python -m magnet_amd.build --dev), the build that honours dev_flags and the
+    MAGNET_* environment switches.  Must be called before the first load(); never called by the package itself."""
+    global LIB_PATH
+    if _lib is not None:
+        raise MagnetError("use_dev_build() must be called before the library is loaded")
+    LIB_PATH = os.path.join(_HERE, "libmagnet_hip_dev.so")
+
+
 def load() -> ctypes.CDLL:
     """Load the library (once).  Raises MagnetError if it has not been built."""
     global _lib

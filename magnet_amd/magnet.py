@@ -173,12 +173,15 @@ class MAGNET(nn.Module):
 
     # -- the hot path proper: everything after the backbones --------------------------------------
     def gnet_input_buffer(self, B, h, w, device):
-        """The split-bf16 zero-bordered channel-last buffer (B*(h+2)*(w+2), ctot) that holds [cost (D, padded to 8) | x_d3 (256)]
+        """The split-bf16 zero-bordered channel-last buffer (B*(h+2)*(w+2), ctot) that holds [cost (D, padded to 64) | x_d3 (256)]
         for the matrix-core G-Net / mask head: (hi, lo, ctot, c_off of x_d3).  A D-Net running on the matrix-core path writes
         its x_d3 output into channels [c_off, c_off+256) of the interior rows and calls match_and_refine(x_d3_in_place=True):
         no NCHW tensor, no repack pass."""
         D = self.n_samples
-        Dp = (D + 7) // 8 * 8
+        # x_d3 starts at a multiple of 64 channels = 128 bytes: its 128-byte pack stores and the convolutions' K slices are line-
+        # aligned (at D = 5 the 8-channel offset of rounds 1-2 made every store straddle two lines: the x_d3 pack ran at 2.0
+        # instead of 5.4 TB/s), and the loop-invariant convolution can read the x_d3 channels alone
+        Dp = (D + 63) // 64 * 64
         if self._stacks is None:
             self._stacks = (ConvStackMFMA(self.g_net.gnet, in_map=[(0, D, 0), (D, 256, Dp)]),
                             ConvStackMFMA(self.mask_head))
@@ -229,7 +232,7 @@ class MAGNET(nn.Module):
 
     def _refine_mfma(self, matcher, ref_gmms, x_d3, n_iter):
         """Inference loop with g_net / mask_head on the matrix cores.  One zero-bordered channel-last buffer
-        (B, h+2, w+2, Ctot) in split-bf16 holds [cost (D, padded to 8) | x_d3 (256)]: x_d3 is packed once and is
+        (B, h+2, w+2, Ctot) in split-bf16 holds [cost (D, padded to 64) | x_d3 (256)]: x_d3 is packed once and is
         read in place by the mask head (channel offset) and by every G-Net iteration; only the D cost channels
         are re-packed per iteration (replaces torch.cat, MAGNET.py:167)."""
         B, _, h, w = ref_gmms.shape
@@ -266,11 +269,10 @@ class MAGNET(nn.Module):
         # convolution over the D cost channels only (K = 9*(256+D) -> 9*round_up(D,32) per iteration).
         partial = None
         if n_iter >= 2 and self.hoist_invariant:
-            # the invariant convolution runs over ALL channels of the cached buffer with the cost-channel weights zeroed: clear
-            # what the previous forward left there, or one frame with a non-finite cost (0 * NaN) would poison every later call
-            gin_hi[:, :Dp].zero_(); gin_lo[:, :Dp].zero_()
+            # the invariant convolution reads the x_d3 channels [Dp, Dp+256) only: nothing the matcher writes (a frame with a non-
+            # finite cost cannot poison it), K = 9 * 256
             main.wait_event(ev_pack)
-            partial = g_stack.run_invariant(gin_hi, gin_lo, ctot, rows, wp, work, Dp)
+            partial = g_stack.run_invariant(gin_hi, gin_lo, ctot, rows, wp, work, D, Dp)
         split_out = self.matcher_path in (0, 2, 4)
         for _ in range(n_iter):
             if split_out:
@@ -285,7 +287,7 @@ class MAGNET(nn.Module):
                 matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out=work["cost"])
                 lib.pack_split(work["cost"], gin_hi, gin_lo, ctot, 0)
             main.wait_event(ev_pack)                                                                 # x_d3 channels are in place
-            g_out, g_ld = g_stack.run(gin_hi, gin_lo, ctot, rows, wp, work, first_addend=partial, n_var=Dp)  # MAGNET.py:62
+            g_out, g_ld = g_stack.run(gin_hi, gin_lo, ctot, rows, wp, work, first_addend=partial, n_var=D, inv_off=Dp)  # MAGNET.py:62
             pred_list.append(lib.gaussian_update_cl(g_out, g_ld, pred_list[-1], h, w))               # MAGNET.py:60-69
         if mask_out is None:
             main.wait_event(ev_pack)

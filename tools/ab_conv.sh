@@ -1,11 +1,12 @@
 #!/bin/bash
 # GPU box: same-box A/B of the convolution K-loop variants (MAGNET_CONV_VARIANT bits, tools/README.md) inside the C2 step.
+# Needs the dev library (python -m magnet_amd.build --dev): the product build ignores the switch.
 # Two passes over the list so that drift shows.  -> gpurun_out/ab_conv_variants.txt (copy to profiles/<round>/)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/ab_conv_variants.txt; : > $O
 for pass in 1 2; do
 for v in 0 16 8 1 2 64 128 32; do
-  MAGNET_CONV_VARIANT=$v timeout 120 python bench.py --no-cpu-baseline --sustain-s 0 2>/dev/null | tail -1 > gpurun_out/_ab.json
+  MAGNET_CONV_VARIANT=$v timeout 120 python bench.py --dev-lib --no-pmc --no-cpu-baseline --sustain-s 0 2>/dev/null | tail -1 > gpurun_out/_ab.json
   python - >> $O <<PY
 import json
 d=json.load(open("gpurun_out/_ab.json"))

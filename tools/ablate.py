@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from magnet_amd import synth, lib
+lib.use_dev_build()
 from magnet_amd.homography import CostVolumeCW
 from magnet_amd.magnet import depth_sampling
 from bench import device_inputs
@@ -22,9 +23,9 @@ fdt = wl.feat_dtype
 # needs a dev build of the library (python -m magnet_amd.build --dev): bits 8.. of `path` travel as MagnetCostVolumeArgs.dev_flags
 R2 = 0x100 << 8                                       # dev flag 0x100: the round-2 production kernels although the quad map is given
 M4, M8, NP2, NP3, NP4 = 0x2000 << 8, 0x1000 << 8, 0x4000 << 8, 0x40000 << 8, 0x80000 << 8
-VG2, VG1 = 0x400000 << 8, 0x800000 << 8
-VARIANTS = [("production (auto) = round-3 kernel", 0), ("r3 VG=2 (68 registers)", VG2), ("r3 VG=1 (59 registers)", VG1), ("r3 3 passes in flight", NP3),
-            ("r3 compiled for 8 waves", M8 | NP2), ("r3 without dot products (timing only)", 0x200 << 8), ("round-2 kernel (fast64)", 4 | R2), ("exact cand", 2),
+VG4, VG1, M7 = 0x400000 << 8, 0x800000 << 8, 0x10000 << 8
+VARIANTS = [("production (auto) = round-3 kernel", 0), ("r3 4 views in flight (6 waves)", VG4), ("r3 1 view in flight (8 waves)", VG1), ("r3 2 views, compiled for 8 waves", M8), ("r3 3 passes in flight", NP3),
+            ("r3 without dot products (timing only)", 0x200 << 8), ("round-2 kernel (fast64)", 4 | R2), ("exact cand", 2),
             ("production (auto), again", 0)]
 for name, path in VARIANTS:
     if split and (path & 0xff) == 3:
@@ -36,13 +37,19 @@ for name, path in VARIANTS:
         cv(ref_gmm=inp["ref_gmms"], k_list=k, **kw)
     except lib.MagnetError as e:
         print(f"{wl.name} {name}: {e}"); continue
-    torch.cuda.synchronize()
-    n = 20
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
+    # the chip's clock / power state drifts for the first second of load (20-launch samples differed by 8 % between the first and
+    # the last variant of one process): ~0.3 s of the same kernel first, then the median of 5 samples of 40 launches
+    for _ in range(300):
         cv(ref_gmm=inp["ref_gmms"], k_list=k, **kw)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
+    torch.cuda.synchronize()
+    n, samples = 40, []
+    for _ in range(5):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            cv(ref_gmm=inp["ref_gmms"], k_list=k, **kw)
+        e1.record(); torch.cuda.synchronize()
+        samples.append(e0.elapsed_time(e1) / n)
+    ms = sorted(samples)[2]
     gbs = wl.algorithmic_bytes() * B / (ms * 1e-3) / 1e9
-    print(f"{wl.name} B={B} {fdt:5s} {'split' if split else 'nchw '} {name:30s}: {ms:8.3f} ms/launch  alg {gbs:7.1f} GB/s = {gbs / 80:5.1f} % of 8 TB/s")
+    print(f"{wl.name} B={B} {fdt:5s} {'split' if split else 'nchw '} {name:30s}: {ms:8.3f} ms/launch (5 samples {min(samples):.3f}..{max(samples):.3f})  alg {gbs:7.1f} GB/s = {gbs / 80:5.1f} % of 8 TB/s")

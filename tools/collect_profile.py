@@ -11,7 +11,7 @@ import shutil
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 src, dst = os.path.join(R, "gpurun_out", tag), os.path.join(R, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
@@ -47,7 +47,7 @@ with open(os.path.join(dst, "pmc_kernels.txt"), "w") as o:
         for c, v in sorted(d.items()):
             o.write(f"  {c:36s} {sum(v) / len(v):18.1f}  n={len(v)}\n")
 
-mk = [k for k in ctr if "cv_fast64_kernel" in k or "cv_fast_kernel" in k]
+mk = sorted((k for k in ctr if "cv_v3_kernel" in k or "cv_fast64_kernel" in k or "cv_fast_kernel" in k), key=lambda k: "cv_v3" not in k)
 out = {"workload": "C2, 64 frames/launch, bf16 features, split-bf16 cost output (inside the bench step)",
        "calib_copy_1GiB_KB": calib, "fetch_correction": fcorr, "write_correction": wcorr}
 if mk:
@@ -58,6 +58,7 @@ if mk:
     us = sum(dur[k]) / len(dur[k]) / 1e3
     out.update({"kernel": k.replace("void magnet::", ""), "traffic_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
                 "algorithmic_bytes_per_launch": 1150156800,
+                "ta_busy_frac": m.get("TA_BUSY_avr", 0) / m["GRBM_GUI_ACTIVE"] if m.get("GRBM_GUI_ACTIVE") else None,
                 "sq": {"valu_insts_per_pixel_view": m.get("SQ_INSTS_VALU", 0) / iters, "salu_insts_per_pixel_view": m.get("SQ_INSTS_SALU", 0) / iters,
                        "vmem_insts_per_pixel_view": m.get("SQ_INSTS_VMEM_RD", 0) / iters, "lds_insts_per_pixel_view": m.get("SQ_INSTS_LDS", 0) / iters,
                        "l1_accesses_per_pixel_view": m.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / iters,
@@ -76,9 +77,17 @@ if st:
         w = csv.writer(o); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows[:16]:
             w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-for f in ("configs.jsonl", "ablate_C2_split.log", "ablate_C2_nchw.log", "valu_rate.txt"):
+for f in ("configs.jsonl", "ablate_C2_split.log", "ablate_C2_nchw.log", "valu_rate.txt", "issue_rate.txt", "gather_rate.txt", "bench_fnet.json",
+          "fnet_layers.txt", "fvolume_bench.jsonl", "bench_end_to_end.json", "kernel_only_C2_nchw.json"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f if f != "configs.jsonl" else "matcher_kernel_only_all_configs.jsonl"))
+st = glob.glob(os.path.join(src, "fvolume_stats", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    rows = list(csv.DictReader(open(st[0])))
+    with open(os.path.join(dst, "fvolume_kernel_stats.csv"), "w") as o:
+        w = csv.writer(o); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows[:12]:
+            w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 os.makedirs(os.path.join(dst, "extra"), exist_ok=True)
 for f in glob.glob(os.path.join(src, "extra", "*.json")):
     shutil.copy(f, os.path.join(dst, "extra", os.path.basename(f)))

@@ -1,20 +1,29 @@
 #!/bin/bash
-# GPU box: the round's official artefacts -> gpurun_out/<tag>/ (tools/collect_profile.py turns them into profiles/<tag>/):
-# bench line, rocprofv3 kernel stats, separate --pmc passes (FETCH_SIZE, WRITE_SIZE, two SQ sets) over the SAME command, the
-# FETCH/WRITE calibration on a 1 GiB device copy, kernel-only runs of every BASELINE config, extra step configurations.
+# GPU box: the round's official artefacts -> gpurun_out/<tag>/ (tools/collect_profile.py turns them into profiles/<tag>/).
+# Every number DESIGN.md quotes must come out of this script (or a file it names under profiles/<tag>/):
+#   bench.json            the contract line (python bench.py: live HIP-event roofline + its own rocprofv3 counter passes)
+#   stats/                rocprofv3 --kernel-trace --stats of the same command
+#   pmc*/                 separate --pmc passes over the same command (FETCH_SIZE, WRITE_SIZE, SQ sets, TA/TCP, TCC)
+#   calib_*               FETCH/WRITE calibration on a 1 GiB device copy
+#   configs.jsonl         matcher alone (--kernel-only) on every BASELINE config
+#   extra/                the step on C3, C4, C5, shipped (D = 5), C2 with packed inputs
+#   bench_fnet.json, fnet_layers.txt          row N3 (tools/bench_fnet.py)
+#   fvolume_bench.jsonl, fvolume_stats/       row N2 (tools/bench_fvolume.py) + its kernel stats
+#   bench_end_to_end.json                     images -> F-Net -> matcher -> G-Net ... (tools/bench_end_to_end.py)
+#   ablate_*.log          matcher variants on the dev library (tools/ablate.py), issue_rate / gather_rate microbenchmarks
 # Every profiler pass has a short timeout: some TA/TCP/TD counter sets hang rocprofv3 on this pool.
-tag=${1:-r2}
+tag=${1:-r3}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$tag; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
-timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --no-cpu-baseline --sustain-s 0 > $O/stats.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python bench.py --no-cpu-baseline --no-pmc --sustain-s 0 > $O/stats.log 2>&1
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" \
             "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_MFMA" \
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA" \
             "TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 90 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc$i -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --sustain-s 0 > $O/pmc$i.log 2>&1 || echo "pmc pass $i failed"
+  timeout 90 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc$i -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --sustain-s 0 > $O/pmc$i.log 2>&1 || echo "pmc pass $i failed"
 done
 for c in FETCH_SIZE WRITE_SIZE; do
 timeout 90 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/calib_$c -o c -- python -c "
@@ -25,14 +34,25 @@ torch.cuda.synchronize()" > $O/calib_$c.log 2>&1
 done
 : > $O/configs.jsonl
 for wl in C1 C2 C4 C5 C2L C2Lf C4L shipped; do
-  timeout 120 python bench.py --kernel-only --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --sustain-s 0 2>/dev/null | tail -1 >> $O/configs.jsonl
+  timeout 120 python bench.py --kernel-only --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --sustain-s 0 2>/dev/null | tail -1 >> $O/configs.jsonl
 done
+timeout 120 python bench.py --kernel-only --nchw-out --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --sustain-s 0 2>/dev/null | tail -1 > $O/kernel_only_C2_nchw.json
 mkdir -p $O/extra
-timeout 120 python bench.py --no-cpu-baseline --packed-inputs > $O/extra/bench_C2_packed_inputs.json 2>/dev/null
-for wl in C3 C4 C5 shipped; do timeout 120 python bench.py --no-cpu-baseline --workload $wl > $O/extra/bench_$wl.json 2>/dev/null; done
-timeout 100 python tools/ablate.py C2 64 split > $O/ablate_C2_split.log 2>&1
-timeout 100 python tools/ablate.py C2 64 > $O/ablate_C2_nchw.log 2>&1
-tools/ubench/valu_rate > $O/valu_rate.txt 2>&1
+timeout 120 python bench.py --no-cpu-baseline --no-pmc --packed-inputs > $O/extra/bench_C2_packed_inputs.json 2>/dev/null
+for wl in C3 C4 C5 shipped; do timeout 120 python bench.py --no-cpu-baseline --no-pmc --workload $wl > $O/extra/bench_$wl.json 2>/dev/null; done
+# rows N3 / N2 / the whole forward
+timeout 200 python tools/bench_fnet.py --frames 8 > $O/bench_fnet.json 2> $O/bench_fnet.err
+timeout 200 python tools/bench_fnet.py --frames 8 --skip-torch --profile-layers > $O/fnet_layers.txt 2>&1
+timeout 200 python tools/bench_fvolume.py > $O/fvolume_bench.jsonl 2> $O/fvolume.err
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fvolume_stats -o s -- python tools/bench_fvolume.py --steps 5 > $O/fvolume_stats.log 2>&1
+timeout 200 python tools/bench_end_to_end.py > $O/bench_end_to_end.json 2> $O/bench_end_to_end.err
+# matcher variants (dev library) + instruction / gather microbenchmarks
+timeout 150 python tools/ablate.py C2 64 split > $O/ablate_C2_split.log 2>&1
+timeout 150 python tools/ablate.py C2 64 > $O/ablate_C2_nchw.log 2>&1
+for u in issue_rate gather_rate; do
+  [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2>/dev/null
+  timeout 120 tools/ubench/$u > $O/$u.txt 2>&1
+done
 find $O -name "*.db" -delete; find $O -name "*_agent_info.csv" -delete
 for f in $(find $O -name "*kernel_trace.csv"); do head -200 $f > $f.head; rm $f; done
-tail -1 $O/bench.json | cut -c1-400
+tail -1 $O/bench.json | cut -c1-600
