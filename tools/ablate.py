@@ -24,7 +24,8 @@ fdt = wl.feat_dtype
 R2 = 0x100 << 8                                       # dev flag 0x100: the round-2 production kernels although the quad map is given
 M4, M8, NP2, NP3, NP4 = 0x2000 << 8, 0x1000 << 8, 0x4000 << 8, 0x40000 << 8, 0x80000 << 8
 VG4, VG1, M7 = 0x400000 << 8, 0x800000 << 8, 0x10000 << 8
-VARIANTS = [("production (auto) = round-3 kernel", 0), ("r3 4 views in flight (6 waves)", VG4), ("r3 1 view in flight (8 waves)", VG1), ("r3 2 views, compiled for 8 waves", M8), ("r3 3 passes in flight", NP3),
+VARIANTS = [("production (auto) = round-3 kernel", 0), ("r3 4 views in flight (6 waves)", VG4), ("r3 1 view in flight (8 waves)", VG1), ("r3 2 views, compiled for 8 waves", M8), ("r3 3 passes in flight", NP3), ("r3 4 passes in flight", NP4), ("r3 capped at 5 workgroups per CU (LDS)", 0x100000 << 8),
+            ("r3 capped at 4 workgroups per CU (LDS)", 0x200000 << 8),
             ("r3 without dot products (timing only)", 0x200 << 8), ("round-2 kernel (fast64)", 4 | R2), ("exact cand", 2),
             ("production (auto), again", 0)]
 for name, path in VARIANTS:

@@ -58,15 +58,17 @@ if mk:
     us = sum(dur[k]) / len(dur[k]) / 1e3
     out.update({"kernel": k.replace("void magnet::", ""), "traffic_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
                 "algorithmic_bytes_per_launch": 1150156800,
-                "ta_busy_frac": m.get("TA_BUSY_avr", 0) / m["GRBM_GUI_ACTIVE"] if m.get("GRBM_GUI_ACTIVE") else None,
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs; TA_BUSY_avr is the mean over the texture-address units
+                "ta_busy_frac": m.get("TA_BUSY_avr", 0) / (m["GRBM_GUI_ACTIVE"] / 8) if m.get("GRBM_GUI_ACTIVE") else None,
+                "clock_ghz_during_kernel": m["GRBM_GUI_ACTIVE"] / 8 / (us * 1e3) if m.get("GRBM_GUI_ACTIVE") and us else None,
                 "sq": {"valu_insts_per_pixel_view": m.get("SQ_INSTS_VALU", 0) / iters, "salu_insts_per_pixel_view": m.get("SQ_INSTS_SALU", 0) / iters,
                        "vmem_insts_per_pixel_view": m.get("SQ_INSTS_VMEM_RD", 0) / iters, "lds_insts_per_pixel_view": m.get("SQ_INSTS_LDS", 0) / iters,
                        "l1_accesses_per_pixel_view": m.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / iters,
-                       "valu_busy_frac": m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024 * us * 1e-6 * 2.4e9) if us else None,
+                       "valu_busy_frac": m.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024 * m["GRBM_GUI_ACTIVE"] / 8) if m.get("GRBM_GUI_ACTIVE") else None,
                        "wave_cycles_waiting_frac": m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
                        "l2_hit_frac": m.get("TCC_HIT_sum", 0) / max(1.0, m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0)),
                        "profiled_launch_us": us,
-                       "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x profiled duration x 2.4 GHz)"}})
+                       "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): busy share of the cycles the chip actually ran"}})
 json.dump(out, open(os.path.join(dst, "traffic_C2.json"), "w"), indent=1)
 
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench_C2.json"))
@@ -77,14 +79,16 @@ if st:
         w = csv.writer(o); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows[:16]:
             w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-for f in ("configs.jsonl", "ablate_C2_split.log", "ablate_C2_nchw.log", "valu_rate.txt", "issue_rate.txt", "gather_rate.txt", "bench_fnet.json",
-          "fnet_layers.txt", "fvolume_bench.jsonl", "bench_end_to_end.json", "kernel_only_C2_nchw.json"):
+for f in ("configs.jsonl", "ablate_C2_split.log", "ablate_C2_nchw.log", "issue_rate.txt", "gather_rate.txt", "bench_fnet.json",
+          "fnet_layers.txt", "fvolume_bench.jsonl", "bench_end_to_end.json", "kernel_only_C2_nchw.json", "parity_stats_gpu_tests.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f if f != "configs.jsonl" else "matcher_kernel_only_all_configs.jsonl"))
-st = glob.glob(os.path.join(src, "fvolume_stats", "**", "*kernel_stats.csv"), recursive=True)
-if st:
+for sdir, oname in (("stats_shipped", "bench_shipped_kernel_stats.csv"), ("fvolume_stats", "fvolume_kernel_stats.csv")):
+    st = glob.glob(os.path.join(src, sdir, "**", "*kernel_stats.csv"), recursive=True)
+    if not st:
+        continue
     rows = list(csv.DictReader(open(st[0])))
-    with open(os.path.join(dst, "fvolume_kernel_stats.csv"), "w") as o:
+    with open(os.path.join(dst, oname), "w") as o:
         w = csv.writer(o); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows[:12]:
             w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])

@@ -34,12 +34,17 @@ torch.cuda.synchronize()" > $O/calib_$c.log 2>&1
 done
 : > $O/configs.jsonl
 for wl in C1 C2 C4 C5 C2L C2Lf C4L shipped; do
-  timeout 120 python bench.py --kernel-only --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --sustain-s 0 2>/dev/null | tail -1 >> $O/configs.jsonl
+  # warm: the chip's clock settles over the first ~0.3 s of load (10-launch samples read 8 % slow)
+  timeout 120 python bench.py --kernel-only --workload $wl --steps 200 --warmup 300 --no-cpu-baseline --no-pmc --sustain-s 0 2>/dev/null | tail -1 >> $O/configs.jsonl
 done
-timeout 120 python bench.py --kernel-only --nchw-out --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --sustain-s 0 2>/dev/null | tail -1 > $O/kernel_only_C2_nchw.json
+timeout 120 python bench.py --kernel-only --nchw-out --steps 200 --warmup 300 --no-cpu-baseline --no-pmc --sustain-s 0 2>/dev/null | tail -1 > $O/kernel_only_C2_nchw.json
 mkdir -p $O/extra
 timeout 120 python bench.py --no-cpu-baseline --no-pmc --packed-inputs > $O/extra/bench_C2_packed_inputs.json 2>/dev/null
 for wl in C3 C4 C5 shipped; do timeout 120 python bench.py --no-cpu-baseline --no-pmc --workload $wl > $O/extra/bench_$wl.json 2>/dev/null; done
+for wl in C2 C5; do timeout 200 python bench.py --no-cpu-baseline --no-pmc --with-fnet --workload $wl --steps 5 --warmup 2 --sustain-s 0 > $O/extra/bench_${wl}_with_fnet.json 2>/dev/null; done
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_shipped -o s -- python bench.py --workload shipped --no-cpu-baseline --no-pmc --sustain-s 0 > $O/stats_shipped.log 2>&1
+# parity statistics printed by the GPU tests (gate flips, error distributions, loop abs_rel): the numbers DESIGN.md section 2 quotes
+timeout 600 python -m pytest tests -m gpu -q -s -k "fast_matcher or golden or parity or rays_poses" 2>&1 | grep -v amdgpu.ids > $O/parity_stats_gpu_tests.txt
 # rows N3 / N2 / the whole forward
 timeout 200 python tools/bench_fnet.py --frames 8 > $O/bench_fnet.json 2> $O/bench_fnet.err
 timeout 200 python tools/bench_fnet.py --frames 8 --skip-torch --profile-layers > $O/fnet_layers.txt 2>&1
