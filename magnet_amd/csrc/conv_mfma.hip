@@ -1196,7 +1196,10 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
         }
         // default: ping-pong x register window, 256-row tile, 8 waves — when there is at least one such tile per CU (256 CUs);
         // fewer rows (single-frame inference: 78 tiles at 120x160) spread better as 128-row tiles of the 4-wave kernel
-        if (win && p.tap_n == 3 && !(p.variant & (16 | 8)) && p.rows >= 256ll * 256) {
+        // — and not for the per-iteration launches of a hoisted first layer (fp32 addend, K = 9 x 32 .. 9 x 64): those are short K
+        // loops between an exposed 128 KB addend load and the tail, where two co-resident 4-wave workgroups overlap better than one
+        // 8-wave workgroup (same-box A/B: 425 vs 464 us at K = 288, 766 vs 804 us at K = 576)
+        if (win && p.tap_n == 3 && !(p.variant & (16 | 8)) && p.rows >= 256ll * 256 && (!p.addend || (p.variant & 256))) {   // dev (MAGNET_CONV_VARIANT=256): 8-wave form for addend launches too
                                                                 // dev (MAGNET_CONV_VARIANT=16): the 4-wave register-window loop below
             if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 2>(p, s);
             if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 2>(p, s);

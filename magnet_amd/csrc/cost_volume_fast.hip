@@ -69,10 +69,12 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
     // PPW > 1 (D <= 32: several pixels per wave iteration): the reference vectors of the wave's 16 pixels live in LDS.  Read
     // from global memory per correlation pass they were half of this path's L1 traffic, and the path is L1-bandwidth-bound
     // (D = 5, fp32 features: 15 TB/s through the 64 B/clk/CU vector-memory path)
-    const int ref_lds = PPW > 1 ? 16 * (int)texel_bytes : 0;
+    // Round 3: only the 8 pixels the next iterations work on are staged (re-staged once in the middle of the wave's 16): with 16 the
+    // fp32 instances sat at 5 workgroups per CU by LDS, and the path is occupancy-sensitive (capped at 4 / 3: +11 % / +36 % time)
+    const int ref_lds = PPW > 1 ? 8 * (int)texel_bytes : 0;
     const int wave_bytes = p.V * 512 + 16 + 1024 + 272 + out_bytes + (LEAD ? 2048 + 32 : 0) + ref_lds;
     unsigned char* wbase = smem + wv * wave_bytes;
-    unsigned char* refl = wbase + (wave_bytes - ref_lds);                             // [16 px][texel_bytes]
+    unsigned char* refl = wbase + (wave_bytes - ref_lds);                             // [8 px][texel_bytes]
     float4*   pvtab = reinterpret_cast<float4*>(wbase);                               // [V][16 px][2]
     float4*   ctab  = reinterpret_cast<float4*>(wbase + p.V * 512);                   // [zero slot for closed lanes | 64 items] x 4 taps
     uint32_t* items = reinterpret_cast<uint32_t*>(wbase + p.V * 512 + 16 + 1024);     // [64 + pad]
@@ -105,14 +107,6 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
     const uint32_t lane_src_off = (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes + (uint32_t)sub * 16u;
     const unsigned char* __restrict__ ref_row = reinterpret_cast<const unsigned char*>(p.ref_feat) +
         ((size_t)b * hw + (size_t)yc * p.w) * texel_bytes;                        // reference features of this pixel row
-    if (PPW > 1) {
-        for (int e = lane; e < 16 * nchunk; e += 64) {        // 16 consecutive pixels of the row are contiguous (channel-last)
-            const int q = e / nchunk, c = e - q * nchunk;
-            const int xr = min(x_base + q, p.w - 1);
-            *reinterpret_cast<uint4*>(refl + e * 16) = *reinterpret_cast<const uint4*>(ref_row + (__umul24((uint32_t)xr, texel_bytes) + (uint32_t)c * 16u));
-        }
-        fwave_lds_fence();
-    }
     const float invV = 1.0f / (float)p.V;
     // view validity (homography.py:97) as a bitmask read ONCE
     unsigned long long vmask = 0ull;
@@ -136,6 +130,17 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
         const int j = jb * DL + j0;
         const float kj = p.k[min(j, p.D - 1)];
         for (int qb = 0; qb < 16 / PPW; ++qb) {
+            if (PPW > 1 && ((qb * PPW) & 7) == 0) {
+                // reference vectors of the next 8 pixels (contiguous in the channel-last row) -> LDS
+                fwave_lds_fence();                                                // the previous 8 pixels' correlation reads are done
+                const int q8 = qb * PPW;
+                for (int e = lane; e < 8 * nchunk; e += 64) {
+                    const int qq = e / nchunk, c = e - qq * nchunk;
+                    const int xr = min(x_base + q8 + qq, p.w - 1);
+                    *reinterpret_cast<uint4*>(refl + e * 16) = *reinterpret_cast<const uint4*>(ref_row + (__umul24((uint32_t)xr, texel_bytes) + (uint32_t)c * 16u));
+                }
+                fwave_lds_fence();
+            }
             const int q = qb * PPW + g;                                           // pixel within the wave's row
             const int x = x_base + q;
             const bool live = (x < p.w) && (y < p.h) && (j < p.D);
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                             const int it = min(IPP * (ps + a) + upair, nitems);   // tail of the last pass: the pad item
                             const uint32_t item = items[it];
                             const unsigned char* sp = src + (__umul24(item & 0xffffffu, texel_bytes) + lane_src_off);
-                            const unsigned char* rp = refl + (__umul24(item >> 26, texel_bytes) + (uint32_t)sub * 16u);   // LDS (PPW > 1 only)
+                            const unsigned char* rp = refl + (__umul24((item >> 26) & 7u, texel_bytes) + (uint32_t)sub * 16u);   // LDS (PPW > 1 only)
 #pragma unroll
                             for (int cc = 0; cc < CPL; ++cc) {
                                 const bool okc = FULL || (sub + LPU * cc < nchunk);
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
 
 template <int DL>
 static size_t fast_lds_bytes(const CvParams& p) {
-    return (size_t)4 * (p.V * 512 + 16 + 1024 + 272 + (p.cost_hi ? 0 : 8 * DL * 4) + (DL < 64 ? 16 * p.F * (p.feat_bf16 ? 2 : 4) : 0));
+    return (size_t)4 * (p.V * 512 + 16 + 1024 + 272 + (p.cost_hi ? 0 : 8 * DL * 4) + (DL < 64 ? 8 * p.F * (p.feat_bf16 ? 2 : 4) : 0));
 }
 
 template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU, int MF, int KS>
@@ -329,8 +334,15 @@ static hipError_t launch_fast(const CvParams& p, hipStream_t stream) {
         if (dv == 3) { hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 12, KS>), grid, block, lds, stream, p); return hipGetLastError(); }
         if (dv == 8) { hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 16, KS>), grid, block, lds + 4 * 2080, stream, p); return hipGetLastError(); }
     }
-    if (p.gate_bits) hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 2, KS>), grid, block, fast_lds_bytes<DL>(p), stream, p);
-    else hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF, KS>), grid, block, fast_lds_bytes<DL>(p), stream, p);
+    size_t lds = fast_lds_bytes<DL>(p);
+#ifdef MAGNET_DEV
+    {   // dev: cap the workgroups per CU by asking for more LDS than the kernel uses (occupancy sensitivity)
+        const int cap = (p.ablate & 0x300000) == 0x300000 ? 3 : (p.ablate & 0x200000) ? 4 : 0;
+        if (cap) { const size_t need = (size_t)160 * 1024 / (cap + 1) + 512; if (lds < need) lds = need; }
+    }
+#endif
+    if (p.gate_bits) hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 2, KS>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF, KS>), grid, block, lds, stream, p);
     return hipGetLastError();
 }
 

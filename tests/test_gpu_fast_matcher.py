@@ -118,11 +118,11 @@ def test_fast_shape_sweep(hip_lib, gpu, V, D, F, fdt):
 
 
 def test_many_views_small_D_lds_budget(hip_lib, gpu):
-    """D <= 32 stages the wave's reference vectors in LDS next to the per-view tables: with V = 22, fp32 F = 64 that is more
+    """D <= 32 stages reference vectors (8 pixels) in LDS next to the per-view tables: with V = 25, fp32 F = 64 that is more
     than 64 KB per workgroup.  `path = 4` (production or error) must say so, `path = 0` must fall back to an exact kernel and
     still give the oracle's volume; V = 12 fits and runs the production kernel."""
     from magnet_amd import lib
-    wl = synth.Workload("views", "7scenes", 10, 23, V=22, D=5, F=64)
+    wl = synth.Workload("views", "7scenes", 10, 23, V=25, D=5, F=64)
     inp = synth.make_inputs(wl, B=1, seed=77, invalid=[(0, 3)])
     k = oracle.depth_sampling(3, wl.D)
     with pytest.raises(lib.MagnetError):
