@@ -1233,6 +1233,8 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
     // 32- and 64-wide 3x3 layers of the trunk: the register-window loop too (their A operand is 2/3 of the DMA pieces of a K
     // step); dev
     // (MAGNET_CONV_VARIANT=8): one A stage per tap
+    // (round 3, with the register window: 256-row tiles = 64 rows per wave for the 64-wide layers 18.5 vs 18.0 ms per 40 images, for the
+    // 32-wide ones 18.1 vs 18.0 — their fragment-read share was not the limit; not kept)
     if (p.cout_pad == 32 && p.tap_n == 3 && !(p.variant & 9))  return launch_conv_nf<2, 1, 128, 1, 0, 256, false, 2>(p, s);
     if (p.cout_pad == 64 && p.tap_n == 3 && !(p.variant & 9))  return launch_conv_nf<4, 1, 128, 1, 0, 256, false, 2>(p, s);
     if (p.cout_pad == 32)  return launch_conv_nf<2, 1, 128, 1>(p, s);

@@ -41,7 +41,10 @@ def main():
     ap.add_argument("--feat-dtype", default="bf16")
     ap.add_argument("--skip-torch", action="store_true")
     ap.add_argument("--profile-layers", action="store_true")
+    ap.add_argument("--dev-lib", action="store_true", help="bind to libmagnet_hip_dev.so (MAGNET_CONV_VARIANT A/B)")
     a = ap.parse_args()
+    if a.dev_lib:
+        lib.use_dev_build()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     psm = fnet.PSMNet(feature_dim=64).eval()
