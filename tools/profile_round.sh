@@ -54,7 +54,7 @@ timeout 200 python tools/bench_end_to_end.py > $O/bench_end_to_end.json 2> $O/be
 # matcher variants (dev library) + instruction / gather microbenchmarks
 timeout 150 python tools/ablate.py C2 64 split > $O/ablate_C2_split.log 2>&1
 timeout 150 python tools/ablate.py C2 64 > $O/ablate_C2_nchw.log 2>&1
-for u in issue_rate gather_rate; do
+for u in issue_rate gather_rate mx_split; do
   [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2>/dev/null
   timeout 120 tools/ubench/$u > $O/$u.txt 2>&1
 done
