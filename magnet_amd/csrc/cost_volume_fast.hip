@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
     const int out_bytes = p.cost_hi ? 0 : OUT_PX * DL * 4;
     const uint32_t texel_bytes = (uint32_t)p.F * (uint32_t)sizeof(FeatT);
     // PPW > 1 (D <= 32: several pixels per wave iteration): the reference vectors of the wave's 16 pixels live in LDS.  Read
-    // from global memory per correlation pass they were half of this path's L1 traffic, and the path is L1-bandwidth-bound
-    // (D = 5, fp32 features: 15 TB/s through the 64 B/clk/CU vector-memory path)
+    // from global memory per correlation pass they were half of this path's L1 traffic, and the path is bound by the L1 gather rate
+    // (D = 5, fp32 features: ~40 B/clk/CU during the correlation phase against the 50 - 55 a pure L2-resident gather reaches)
     // Round 3: only the 8 pixels the next iterations work on are staged (re-staged once in the middle of the wave's 16): with 16 the
     // fp32 instances sat at 5 workgroups per CU by LDS, and the path is occupancy-sensitive (capped at 4 / 3: +11 % / +36 % time)
     const int ref_lds = PPW > 1 ? 8 * (int)texel_bytes : 0;
