@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     constexpr bool SPLIT = (OPT & 64) != 0;               // the split-bf16 channel-last output form only (cost_hi given): no NCHW staging code, fewer live scalars
     constexpr int NPX = V3_NPX;
     constexpr int IPP = 64 / (4 * LPU);                   // items per correlation pass
-    constexpr bool QF = LPU == 4;                         // an item's four taps share a 16-lane row: correlations stored in quad form (cv_runs.hpp)
+    constexpr bool QF = LPU == 4 && !(OPT & 128);                         // an item's four taps share a 16-lane row: correlations stored in quad form (cv_runs.hpp)
     constexpr int NPASS = ((OPT >> 8) & 15) ? ((OPT >> 8) & 15) : V3_NPASS_DEFAULT;   // passes fetched together
     constexpr int CSTR = LPU * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -347,6 +347,7 @@ static hipError_t launch_v3_v(const CvParams& p0, hipStream_t stream) {
     constexpr int MW2 = CPL >= 4 ? 4 : (MINW > 5 ? 5 : MINW);             // the NCHW-output and gate-bit instances carry more live values: one wave per SIMD less instead of scratch
 #ifdef MAGNET_DEV
     if (p.ablate & 0x200) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MW2, LPU, VG, NP | 2>), grid, block, lds, stream, p); return hipGetLastError(); }      // no dot products (timing only)
+    if (p.cost_hi && (p.ablate & 0x20000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, NP | 64 | 128>), grid, block, lds, stream, p); return hipGetLastError(); }   // dev: four-weight combine instead of the quad-form slots
     if (p.cost_hi && (p.ablate & 0x4000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x200>), grid, block, lds, stream, p); return hipGetLastError(); }
     if (p.cost_hi && (p.ablate & 0x40000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x300>), grid, block, lds, stream, p); return hipGetLastError(); }
     if (p.cost_hi && (p.ablate & 0x80000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x400>), grid, block, lds, stream, p); return hipGetLastError(); }
@@ -379,6 +380,10 @@ hipError_t launch_cv_v3(const CvParams& p, hipStream_t stream, bool* handled) {
     *handled = false;
     const size_t esz = p.feat_bf16 ? 2 : 4;
     if (p.D <= 32 || !p.src_gmq) return hipSuccess;
+    // Full-resolution matching grids (w > 512: the grid-stress shapes C2L / C4L, 14 instead of 3.5 items per (pixel, view)) are
+    // decided by the correlation of long item lists, where the round-2 kernel (16 items per batch, one list for all views) is
+    // better: C2L 2.33 vs 2.84 ms, C4L 1.54 vs 1.63 ms (same session, warm); at w <= 304 this kernel wins (C4 0.75 vs 0.95 ms)
+    if (p.w > 512 && !(p.ablate & 0x4)) return hipSuccess;                                 // dev 0x4: this kernel anyway
     if ((size_t)p.V * p.B * (size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets over all views
     if ((size_t)(p.h + 2) * (p.w + 2) >= ((size_t)1 << 24)) return hipSuccess;                                    // quad keys exact in fp32
     const int nchunk = (int)(p.F * esz / 16);

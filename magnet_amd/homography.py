@@ -150,7 +150,10 @@ class CostVolumeCW:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
         D = d_volume.shape[1] if d_volume is not None else len(k_list)
-        quad = (self.path & 0xff) in (0, 4) and D > 32 and d_volume is None and stats is None
+        # the D > 32 production kernel reads the quad-form (mu, sigma) map; matching grids wider than 512 (long epipolar segments)
+        # go to the round-2 kernel, which reads the interleaved one (cost_volume_v3.hip:launch_cv_v3 decides; mirrored here only
+        # to pack the right map first — a wrong guess costs one MAGNET_E_SHAPE retry below, not a wrong result)
+        quad = (self.path & 0xff) in (0, 4) and D > 32 and d_volume is None and stats is None and self.w <= 512
         if quad and self._gmm_quad is None:
             self._gmm_quad = lib.pack_gmm_quad(self._gmm_nchw)
         if not quad and self._gmm_pad is None:
