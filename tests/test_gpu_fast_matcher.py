@@ -134,6 +134,36 @@ def test_many_views_small_D_lds_budget(hip_lib, gpu):
     _check(synth.make_inputs(wl12, B=1, seed=78), k, gpu, label="V=12 D=5")
 
 
+def test_wide_grid_runs_the_batched_view_kernel(hip_lib, gpu):
+    """Matching grids wider than 512 (full-resolution grids: long epipolar segments) are routed to the round-2 D > 32 kernel
+    (cost_volume_fast64.hip), which reads the interleaved (mu, sigma) map: same tolerance contract; both output forms."""
+    wl = synth.Workload("wide", "kitti", 6, 528, V=3, D=48, F=64)
+    inp = synth.make_inputs(wl, B=2, seed=91, invalid=[(1, 2)])
+    k = oracle.depth_sampling(3, wl.D)
+    _check(inp, k, gpu, label="wide grid (w = 528) fp32")
+    _check(synth.make_inputs(wl, B=1, seed=92, round_bf16=True), k, gpu, fdt="bf16", label="wide grid (w = 528) bf16")
+
+
+def test_quad_only_call_on_a_shape_the_quad_kernel_declines_is_E_SHAPE(hip_lib, gpu):
+    """C ABI contract (include/magnet_hip.h): with only the quad-form (mu, sigma) map given, a shape that ends on a kernel reading
+    the interleaved map returns MAGNET_E_SHAPE — the one code a caller may answer by packing the other map and calling again."""
+    from magnet_amd import lib
+    wl = synth.Workload("wide", "kitti", 6, 528, V=2, D=40, F=64)
+    d = to_dev(synth.make_inputs(wl, B=1, seed=93), gpu)
+    k = oracle.depth_sampling(3, wl.D)
+    ref_cl = lib.pack_features(d["ref_feat"], lib.feat_enum("fp32"), pad=0)
+    src_pad = lib.pack_features(d["nghbr_feat"], lib.feat_enum("fp32"), pad=1)
+    quad = lib.pack_gmm_quad(d["nghbr_gmms"])
+    intr = d["cam_intrins"]
+    with pytest.raises(lib.MagnetError) as ei:
+        lib.cost_volume_cw(ref_cl, src_pad, None, d["nghbr_poses"], d["is_valid"].to(gpu).int(), intr["intM"].to(gpu).float(),
+                           intr["unit_ray_array_2D"].to(gpu).float().contiguous(), 5.0, ref_gmm=d["ref_gmms"], k_list=k, path=4, src_gmm_quad=quad)
+    assert ei.value.code == lib.E_SHAPE
+    both = lib.cost_volume_cw(ref_cl, src_pad, lib.pack_gmm(d["nghbr_gmms"]), d["nghbr_poses"], d["is_valid"].to(gpu).int(), intr["intM"].to(gpu).float(),
+                              intr["unit_ray_array_2D"].to(gpu).float().contiguous(), 5.0, ref_gmm=d["ref_gmms"], k_list=k, path=4, src_gmm_quad=quad)
+    assert torch.isfinite(both).all()
+
+
 def test_fast_nan_and_degenerate_inputs(hip_lib, gpu):
     """NaN / zero sigma / zero depth in the reference gmm and a singular pose (test_gpu_parity.py's case)."""
     wl = synth.Workload("nan", "scannet", 12, 16, V=2, D=8, F=8)
