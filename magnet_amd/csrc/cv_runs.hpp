@@ -64,23 +64,8 @@ __device__ __forceinline__ float v3_quadform16(float x) {
     return x;
 }
 
-// Leaders (first lanes of runs, ballot L) whose run holds at least one open gate (ballot G; every G lane belongs to a run).
-// In bit-reversed order a run is [.., leader] with the leader on top: adding the run's gate bits to the all-ones run body
-// carries into the leader's (zero) position exactly when the body holds a gate bit; the leader's own gate bit is OR-ed in.
-__device__ __forceinline__ uint64_t v3_open_leaders(uint64_t G, uint64_t L) {
-    const uint64_t Gr = __builtin_bitreverse64(G), Lr = __builtin_bitreverse64(L);
-    const uint64_t Z = ~Lr;
-    const uint64_t S = (Gr & Z) + Z;
-    return __builtin_bitreverse64((S & Lr) | (Gr & Lr));
-}
 
-// s_and_saveexec form of the masked stores (2 scalar instructions around the store instead of 3)
-template <int OFF>
-__device__ __forceinline__ void v3_st1_mask(uint64_t mask, uint32_t addr, uint32_t val) {
-    uint64_t save;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3 offset:%4\n\ts_mov_b64 exec, %0"
-                 : "=&s"(save) : "s"(mask), "v"(addr), "v"(val), "n"(OFF) : "memory", "scc");
-}
+// s_and_saveexec form of a masked store (2 scalar instructions around the store instead of 3)
 __device__ __forceinline__ void v3_st2_mask(uint64_t mask, uint32_t addr, uint32_t lo, uint32_t hi) {
     uint64_t save;
     const uint64_t val = ((uint64_t)hi << 32) | lo;
@@ -88,10 +73,5 @@ __device__ __forceinline__ void v3_st2_mask(uint64_t mask, uint32_t addr, uint32
                  : "=&s"(save) : "s"(mask), "v"(addr), "v"(val) : "memory", "scc");
 }
 
-
-// First open lane of every stretch of open gates inside a run (G = open gates, L = run leaders; a lane continues its
-// predecessor's stretch when that lane is open and the lane is no leader).  One item per such lane: a run whose gate opens,
-// closes and opens again is listed twice (same slot, same values — harmless), everything else once.  3 scalar instructions.
-__device__ __forceinline__ uint64_t v3_first_open(uint64_t G, uint64_t L) { return G & (~(G << 1) | L); }
 
 }  // namespace magnet
