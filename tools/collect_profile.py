@@ -39,7 +39,7 @@ GiB_KB = float(1 << 20)
 fcorr = GiB_KB / calib["FETCH_SIZE"] if calib["FETCH_SIZE"] else 2.0
 wcorr = GiB_KB / calib["WRITE_SIZE"] if calib["WRITE_SIZE"] else 1.0
 with open(os.path.join(dst, "pmc_kernels.txt"), "w") as o:
-    o.write(f"# mean per dispatch over the rocprofv3 --pmc passes of `python bench.py --steps 3 --warmup 1` (tools/profile_round.sh)\n"
+    o.write(f"# mean per dispatch over the rocprofv3 --pmc passes of `python bench.py --steps 20 --warmup 5` (tools/profile_round.sh)\n"
             f"# calibration copy (1 GiB read + 1 GiB write): FETCH_SIZE {calib['FETCH_SIZE']} KB, WRITE_SIZE {calib['WRITE_SIZE']} KB"
             f" -> corrections x{fcorr:.3f}, x{wcorr:.3f}\n")
     for k, d in sorted(ctr.items()):
@@ -69,6 +69,16 @@ if mk:
                        "l2_hit_frac": m.get("TCC_HIT_sum", 0) / max(1.0, m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0)),
                        "profiled_launch_us": us,
                        "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): busy share of the cycles the chip actually ran"}})
+# the same kernel alone and warm (pmc_alone pass): last 100 dispatches
+al = [r for r in rows_of(os.path.join(src, "pmc_alone", "**", "*counter_collection.csv")) if "cv_v3_kernel" in r["Kernel_Name"]]
+if al:
+    g = [r for r in al if r["Counter_Name"] == "GRBM_GUI_ACTIVE"][-100:]
+    t = [r for r in al if r["Counter_Name"] == "TA_BUSY_avr"][-100:]
+    if g:
+        cyc = sum(float(r["Counter_Value"]) for r in g) / len(g) / 8
+        ns = sum(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in g) / len(g)
+        out["alone_warm"] = {"profiled_launch_us": ns / 1e3, "clock_ghz_during_kernel": cyc / ns,
+                             "ta_busy_frac": (sum(float(r["Counter_Value"]) for r in t) / len(t) / cyc) if t else None}
 json.dump(out, open(os.path.join(dst, "traffic_C2.json"), "w"), indent=1)
 
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench_C2.json"))

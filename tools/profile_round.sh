@@ -11,7 +11,8 @@
 #   fvolume_bench.jsonl, fvolume_stats/       row N2 (tools/bench_fvolume.py) + its kernel stats
 #   bench_end_to_end.json                     images -> F-Net -> matcher -> G-Net ... (tools/bench_end_to_end.py)
 #   ablate_*.log          matcher variants on the dev library (tools/ablate.py), issue_rate / gather_rate microbenchmarks
-# Every profiler pass has a short timeout: some TA/TCP/TD counter sets hang rocprofv3 on this pool.
+# Every profiler pass has a short timeout: some TA/TCP/TD counter sets hang rocprofv3 on this pool.  The --pmc passes run the
+# contract's own 5 + 20 steps, so that the clock / busy counters describe the chip state the bench line was measured in.
 tag=${1:-r3}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$tag; mkdir -p $O
@@ -23,8 +24,10 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" \
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA" \
             "TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 90 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc$i -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --sustain-s 0 > $O/pmc$i.log 2>&1 || echo "pmc pass $i failed"
+  timeout 90 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc$i -o p -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --sustain-s 0 > $O/pmc$i.log 2>&1 || echo "pmc pass $i failed"
 done
+# the matcher alone and warm: the clock it gets when the matrix-core kernels are not around (300 warm-up launches first)
+timeout 120 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TA_BUSY_avr --output-format csv -d $O/pmc_alone -o p -- python bench.py --kernel-only --steps 200 --warmup 300 --no-cpu-baseline --no-pmc --sustain-s 0 > $O/pmc_alone.log 2>&1 || echo "pmc alone failed"
 for c in FETCH_SIZE WRITE_SIZE; do
 timeout 90 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/calib_$c -o c -- python -c "
 import torch
