@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--conv-backend", default="mfma", choices=["mfma", "torch"],
                     help="g_net/mask_head convolutions: bf16x3 MFMA kernel (default) or nn.Conv2d on MIOpen")
     ap.add_argument("--no-fuse-tail", action="store_true", help="one launch per 1x1 layer instead of the fused epilogue")
+    ap.add_argument("--no-fuse-upsample", action="store_true", help="mask head writes its (B,144,h,w) logits and a separate launch upsamples "
+                    "(default: the mask head's last layer writes the upsampled predictions itself)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph (magnet_amd/graph.py; small batches)")
     ap.add_argument("--overlap", action="store_true", help="run the mask head on a side stream (measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -327,6 +329,7 @@ def main():
     model.overlap_mask_head = a.overlap
     model.overlap_pack = a.overlap_pack
     model.fuse_conv_tail = not a.no_fuse_tail
+    model.fuse_upsample = not a.no_fuse_upsample
     bcast_bytes = mdist.broadcast_module_(model, src=0)   # the one RCCL collective (weights), xGMI
 
     inp = device_inputs(wl, B, seed=1000 + rank, device=device)
@@ -486,7 +489,7 @@ def main():
                                   "backbone outputs as the reference's NCHW fp32 tensors (pack passes inside the step)"),
                        "frames_per_gpu_per_step": B, "step": "kernel-only" if a.kernel_only else
                        ("F-Net on every image + " if a.with_fnet else "") +
-                       ("pack + I x (fused cost volume + G-Net + Gaussian update) + mask head + convex upsample; convs on "
+                       ("pack + I x (fused cost volume + G-Net + Gaussian update) + mask head with the convex upsampling in its last layer; convs on "
                         + ("the bf16x3 MFMA kernel" if a.conv_backend == "mfma" else "MIOpen fp32")),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; "
                                       f"one RCCL weight broadcast ({bcast_bytes} B)"},

@@ -38,7 +38,7 @@ extern "C" {
 
 #define MAGNET_API __attribute__((visibility("default")))
 
-#define MAGNET_HIP_VERSION 300            /* major*10000 + minor*100 + patch */
+#define MAGNET_HIP_VERSION 301            /* major*10000 + minor*100 + patch */
 
 enum {                                     /* storage dtype of channel-last feature maps */
     MAGNET_FEAT_F32  = 0,
@@ -243,6 +243,14 @@ typedef struct MagnetConvArgs {
                                               hidden (rows,128) tensors never reach HBM. */
     const float *tail_bias;
     int32_t      tail_cout_pad;            /* 16, 128 or 144 */
+    /* v301 — fused learned convex upsampling (models/MAGNET.py:15-27,172-173), for the mask head's stack (tail_cout_pad = 144):
+     * the tail's last layer keeps the (rows, 144) mask logits in registers, soft-maxes the 9 neighbour weights of each of the 16
+     * sub-pixels and writes the x4-upsampled maps itself: up_depth (up_npred, up_B, 2, up_h, up_w) fp32 -> up_out (up_npred, up_B,
+     * 2, 4 up_h, 4 up_w) fp32.  Requires rows = up_B * (up_h + 2) * (up_w + 2), wp = up_w + 2; out_f32 is not written.
+     * All zero / NULL = the plain tail above (magnet_upsample_depth_cl_n then does this step from out_f32). */
+    const float *up_depth;
+    float       *up_out;
+    int32_t      up_npred, up_B, up_h, up_w;
 } MagnetConvArgs;                          /* out_mode 2: one bf16 plane (round-to-nearest-even) at out_hi */
 
 MAGNET_API int magnet_conv_mfma(const MagnetConvArgs *args, void *stream);

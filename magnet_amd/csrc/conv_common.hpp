@@ -30,6 +30,12 @@ struct ConvParams {
     // workgroup's tile before it leaves the CU; weights [128][128],[128][128],[tail_cout][128] concatenated, bias likewise
     const uint16_t* tail_w_hi; const uint16_t* tail_w_lo; const float* tail_bias;
     int tail_cout;                                    // 16, 128 or 144; result fp32 (rows, tail_cout) at out_f32
+    // fused convex upsampling (tail_cout == 144 only; models/MAGNET.py:15-27): the tail's last layer keeps its (rows, 144) mask
+    // logits in registers, soft-maxes the 9 neighbour weights of each of the 16 sub-pixels and writes the x4-upsampled (mu, sigma)
+    // of up_npred stacked predictions: depth (up_npred, B, 2, up_h, up_w) -> up_out (up_npred, B, 2, 4 up_h, 4 up_w); nothing is
+    // written to out_f32.  Rows are positions of (B, up_h + 2, up_w + 2) grids (wp = up_w + 2).
+    const float* up_depth; float* up_out;
+    int up_npred, up_h, up_w, up_B;
     int variant;                                      // dev: bit 1 = 8-wave ping-pong K loop (conv_mfma.hip, PP) instead of the default
 };
 

@@ -145,6 +145,7 @@ class MAGNET(nn.Module):
             raise lib.MagnetError(f"conv_backend must be 'mfma' or 'torch', got {conv_backend!r}")
         self.conv_backend = conv_backend
         self._work = {}                # cached device workspaces of the MFMA conv path, keyed by shape
+        self.fuse_upsample = True      # mask head's last layer writes the upsampled predictions itself (no (B,144,h,w) mask in HBM)
         self.hoist_invariant = True    # I >= 2: compute the x_d3 part of G-Net's first layer once per forward
         self._stacks = None
         # mask head on a side stream next to matcher + G-Net.  Measured on MI355X: no gain (10.15 vs 10.05 ms per C2 step) —
@@ -291,6 +292,15 @@ class MAGNET(nn.Module):
             pred_list.append(lib.gaussian_update_cl(g_out, g_ld, pred_list[-1], h, w))               # MAGNET.py:60-69
         if mask_out is None:
             main.wait_event(ev_pack)
+            if self.fuse_upsample and n_iter == 1 and self.downsample_ratio == 4 and m_stack.can_fuse_upsample(dev):
+                # MAGNET.py:172-173 in one launch: the mask head's last 1x1 layer soft-maxes its own logits and writes the x4-upsampled
+                # prediction; the (B, 144, h, w) mask never reaches HBM.  One prediction only: with I = 3 the per-tile epilogue (3 x 18
+                # neighbour loads at the end of a tile, nothing left to overlap them with) costs more than the separate launch that
+                # reads the mask once for all predictions (measured: C2 +1 %, shipped D = 5 / I = 3 -0.8 %)
+                d = torch.stack(pred_list[1:])
+                outs = torch.empty((d.shape[0], B, 2, 4 * h, 4 * w), dtype=torch.float32, device=dev)
+                m_stack.run(gin_hi[:, Dp:], gin_lo[:, Dp:], ctot, rows, wp, work.setdefault("mask", {}), upsample=(d, outs))
+                return [outs[i] for i in range(outs.shape[0])]
             mask_out = m_stack.run(gin_hi[:, Dp:], gin_lo[:, Dp:], ctot, rows, wp, work.setdefault("mask", {}))      # MAGNET.py:172
         else:
             main.wait_event(ev_mask)

@@ -67,6 +67,40 @@ def test_conv_stack_chip_filling_shape_matches_fp32(hip_lib, gpu, cin, cout):
     assert torch.isfinite(got).all() and err <= 2e-5 * max(1.0, scale)
 
 
+@pytest.mark.parametrize("B,h,w,n_pred", [(1, 9, 21, 1), (2, 12, 16, 3), (4, 120, 160, 2)])
+def test_mask_head_with_fused_upsampling_equals_the_two_launch_form(hip_lib, gpu, B, h, w, n_pred):
+    """MAGNET.py:172-173 in one launch (the mask head's last 1x1 layer soft-maxes its logits and writes the x4-upsampled
+    predictions) against mask head -> (rows, 144) fp32 -> magnet_upsample_depth_cl_n: same arithmetic in the same order, so the
+    outputs must be bit-identical.  Small shapes run the 4-wave kernel, 4 x 120 x 160 the 8-wave one (ragged last tile)."""
+    from magnet_amd import lib
+    from magnet_amd.convnet import ConvStackMFMA
+    seq = _stack(256, 144, seed=17).to(gpu)
+    st = ConvStackMFMA(seq)
+    assert st.can_fuse_upsample(gpu)
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, 256, h, w, generator=g)
+    depths = [torch.cat([torch.rand(B, 1, h, w, generator=g) * 5 + 0.5, torch.rand(B, 1, h, w, generator=g) * 0.5 + 0.05], dim=1).to(gpu)
+              for _ in range(n_pred)]
+    rows = B * (h + 2) * (w + 2)
+    hi = torch.zeros((rows, 256), dtype=torch.bfloat16, device=gpu); lo = torch.zeros_like(hi)
+    lib.pack_split(x.to(gpu), hi, lo, 256, 0)
+    mask, ld = st.run(hi, lo, 256, rows, w + 2, {})
+    ref = lib.upsample_depth_cl_n(depths, mask, ld)
+    d = torch.stack(depths)
+    outs = torch.full((n_pred, B, 2, 4 * h, 4 * w), float("nan"), dtype=torch.float32, device=gpu)
+    none, ld2 = st.run(hi, lo, 256, rows, w + 2, {}, upsample=(d, outs))
+    torch.cuda.synchronize()
+    assert none is None and ld2 == 144
+    for i in range(n_pred):
+        assert torch.equal(outs[i], ref[i]), f"prediction {i}: max|d| = {(outs[i] - ref[i]).abs().max().item():.3e}"
+    # and against the reference's own formulation on the CPU (MAGNET.py:15-27)
+    m = mask.view(B, h + 2, w + 2, ld)[:, 1:-1, 1:-1, :144].permute(0, 3, 1, 2).cpu()
+    mk = torch.softmax(m.view(B, 1, 9, 4, 4, h, w), dim=2)
+    up = torch.nn.functional.unfold(depths[0].cpu(), [3, 3], padding=1).view(B, 2, 9, 1, 1, h, w)
+    want = torch.sum(mk * up, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2, 4 * h, 4 * w)
+    assert (outs[0].cpu() - want).abs().max().item() <= 5e-6
+
+
 def test_conv_stack_channel_map_odd_D(hip_lib, gpu):
     """G-Net with D = 5: cost channels [0,5), x_d3 at channel offset 8 of the 288-wide buffer."""
     seq = _stack(256 + 5, 2, seed=3)
