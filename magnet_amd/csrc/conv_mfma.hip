@@ -183,10 +183,11 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
 // tails ran at half the K loop's efficiency) and reads every row's activations from LDS (256 B/clk, cheap).  A remainder
 // fragment (TAILN % 4 == 1: the 16-channel G-Net head, the 9th fragment of the 144-channel mask head) is row-split over the
 // waves.  The layer's output replaces its input in place: one barrier after the last read, one after the last write.
-template <int TAILN, bool LAST, int ROWS, int NW = 4>
+template <int TAILN, bool LAST, int ROWS, int NW = 4, bool UP = false>
 __device__ __forceinline__ void tail_layer_cols(const uint16_t* __restrict__ w_hi, const uint16_t* __restrict__ w_lo,
                                                 const float* __restrict__ bias, unsigned char* act_hi, unsigned char* act_lo,
-                                                float* __restrict__ out, int out_ld, long long row0, long long rows, int lane, int wv) {
+                                                float* __restrict__ out, int out_ld, long long row0, long long rows, int lane, int wv,
+                                                const UpArgs up = UpArgs{nullptr, nullptr, 0, 0, 0, 0}) {
     // NW waves: wave w owns output fragments w, w + NW, ...; MA row blocks, read from LDS 8 at a time
     constexpr int NJ = TAILN / NW, REM = TAILN % NW, MA = ROWS / 16, MR = MA / NW;   // MR: remainder-fragment row blocks per wave
     static_assert(REM <= 1 && MA % 8 == 0 && MA % NW == 0, "one row-split remainder fragment at most");
@@ -241,6 +242,85 @@ __device__ __forceinline__ void tail_layer_cols(const uint16_t* __restrict__ w_h
                 accr[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, rh, accr[m], 0, 0, 0);
             }
         }
+    }
+    if constexpr (UP) {
+        // ---- learned convex upsampling (models/MAGNET.py:15-27) behind the mask head's last layer, column-owned: the 144 logits of a
+        // position sit in 9 different waves (fragment n = neighbour n of the 3x3 window), so they meet in LDS: 128 rows x 144 fp32 at
+        // a time in the (now dead) activation tile, then one thread per (position, sub-pixel row i) does what upsample_cl_kernel does
+        // — same arithmetic, same order: bit-identical — with the mask read from LDS instead of HBM.
+        static_assert(TAILN == 9 && LAST && ROWS % 128 == 0, "mask head's last layer");
+        constexpr int SP = 148;                               // stage row pitch in floats: 16 rows x 4 quads of a fragment store hit distinct banks
+        float* stage = reinterpret_cast<float*>(act_hi);      // 128 x 148 x 4 B = 74 KB <= ROWS x 512 B
+        const int wp = up.w + 2, img_rows = (up.h + 2) * wp;
+        const size_t hw = (size_t)up.h * up.w;
+        const int tid = wv * 64 + lane;
+        for (int half = 0; half < ROWS / 128; ++half) {
+            __syncthreads();                                  // every wave is done with the activation tile / with the previous half's stage
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int m = 0; m < MA; ++m) {
+                    if (m / 8 != half) continue;
+                    const int ch = (wv + NW * j) * 16 + (lane >> 4) * 4, srow = (m & 7) * 16 + (lane & 15);
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias + ch);
+                    *reinterpret_cast<float4*>(stage + srow * SP + ch) =
+                        make_float4(acc[j][m][0] + b4.x, acc[j][m][1] + b4.y, acc[j][m][2] + b4.z, acc[j][m][3] + b4.w);
+                }
+            if constexpr (REM) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const int mrow = wv * MR + m;
+                    if (mrow / 8 != half) continue;
+                    const int ch = NJ * NW * 16 + (lane >> 4) * 4, srow = (mrow & 7) * 16 + (lane & 15);
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias + ch);
+                    *reinterpret_cast<float4*>(stage + srow * SP + ch) =
+                        make_float4(accr[m][0] + b4.x, accr[m][1] + b4.y, accr[m][2] + b4.z, accr[m][3] + b4.w);
+                }
+            }
+            __syncthreads();
+            for (int t = tid; t < 128 * 4; t += NW * 64) {    // (position of this half, sub-pixel row i)
+                const int srow = t >> 2, i = t & 3;
+                const long long row = row0 + half * 128 + srow;
+                const int b = (int)((unsigned)row / (unsigned)img_rows);                  // rows < 2^31 (checked by the API)
+                const int rem = (int)((unsigned)row - (unsigned)b * (unsigned)img_rows);
+                const int yy = rem / wp, xx = rem - yy * wp;
+                if (row >= rows || yy < 1 || yy > up.h || xx < 1 || xx > up.w) continue;  // border position: nothing to write
+                const int y = yy - 1, x = xx - 1;
+                const float* mrow = stage + srow * SP + i * 4;
+                float4 mv[9];
+                float4 mx = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
+#pragma unroll
+                for (int n = 0; n < 9; ++n) {
+                    mv[n] = *reinterpret_cast<const float4*>(mrow + n * 16);
+                    mx.x = fmaxf(mx.x, mv[n].x); mx.y = fmaxf(mx.y, mv[n].y); mx.z = fmaxf(mx.z, mv[n].z); mx.w = fmaxf(mx.w, mv[n].w);
+                }
+                float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int n = 0; n < 9; ++n) {
+                    mv[n].x = __expf(mv[n].x - mx.x); mv[n].y = __expf(mv[n].y - mx.y);
+                    mv[n].z = __expf(mv[n].z - mx.z); mv[n].w = __expf(mv[n].w - mx.w);
+                    den.x += mv[n].x; den.y += mv[n].y; den.z += mv[n].z; den.w += mv[n].w;
+                }
+                const float4 inv = make_float4(1.0f / den.x, 1.0f / den.y, 1.0f / den.z, 1.0f / den.w);
+#pragma unroll
+                for (int n = 0; n < 9; ++n) { mv[n].x *= inv.x; mv[n].y *= inv.y; mv[n].z *= inv.z; mv[n].w *= inv.w; }
+                for (int pi = 0; pi < up.npred; ++pi) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const size_t plane = ((size_t)pi * up.B + b) * 2 + c;
+                        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int n = 0; n < 9; ++n) {
+                            const int y2 = y + n / 3 - 1, x2 = x + n % 3 - 1;
+                            const float dv = (y2 >= 0 && y2 < up.h && x2 >= 0 && x2 < up.w) ? up.depth[plane * hw + (size_t)y2 * up.w + x2] : 0.f;
+                            a.x += mv[n].x * dv; a.y += mv[n].y * dv; a.z += mv[n].z * dv; a.w += mv[n].w * dv;
+                        }
+                        *reinterpret_cast<float4*>(up.out + (plane * up.h * 4 + (size_t)y * 4 + i) * ((size_t)up.w * 4) + (size_t)x * 4) = a;
+                    }
+                }
+            }
+        }
+        return;
     }
     if constexpr (!LAST) __syncthreads();                     // every wave is done reading the layer's input: overwrite it in place
     auto emit = [&](const f32x4_t& a, int n, int mrow) {
@@ -1099,9 +1179,10 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
                 tail_layer_cols<8, false, CV_BM, NW>(p.tail_w_hi + 128 * 128, p.tail_w_lo + 128 * 128, p.tail_bias + 128, act_hi, act_lo, nullptr,
                                                      0, row0, p.rows, lane, wv);
                 if constexpr (TAIL == 9) {
-                    if (p.up_out) {                           // fused convex upsampling: the last layer row-owned (a position's 144 logits in one lane group)
-                        tail_layer<9, true, 2, true>(p.tail_w_hi + 2 * 128 * 128, p.tail_w_lo + 2 * 128 * 128, p.tail_bias + 256, act_hi, act_lo, nullptr, 0,
-                                                     row0, p.rows, lane, wv, UpArgs{p.up_depth, p.up_out, p.up_npred, p.up_h, p.up_w, p.up_B});
+                    if (p.up_out) {                           // fused convex upsampling: the 144 logits meet in LDS, never in HBM
+                        tail_layer_cols<9, true, CV_BM, NW, true>(p.tail_w_hi + 2 * 128 * 128, p.tail_w_lo + 2 * 128 * 128, p.tail_bias + 256, act_hi,
+                                                                  act_lo, nullptr, 0, row0, p.rows, lane, wv,
+                                                                  UpArgs{p.up_depth, p.up_out, p.up_npred, p.up_h, p.up_w, p.up_B});
                         return;
                     }
                 }
@@ -1226,6 +1307,7 @@ static hipError_t launch_conv_nf(const ConvParams& p, hipStream_t s) {
     const dim3 grid((unsigned)((p.rows + BM - 1) / BM), (unsigned)(p.cout_pad / (NF * 16))), block(NT);
     size_t lds = conv_lds_bytes<NF, WN, BM, SPB, NT, PP, WIN>();
     if (TAIL > 0 && lds < (size_t)BM * 512) lds = (size_t)BM * 512;     // the fused tail's activation tile: BM rows x 256 B x (hi, lo)
+    if (TAIL == 9 && lds < (size_t)128 * 148 * 4) lds = (size_t)128 * 148 * 4;   // fused upsampling: 128 rows x 144 logits (+4 pad) fp32 (two 4-wave workgroups still fit a CU)
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {          // > 64 KiB of dynamic LDS needs the opt-in attribute
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP, WIN>),

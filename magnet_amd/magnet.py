@@ -292,11 +292,9 @@ class MAGNET(nn.Module):
             pred_list.append(lib.gaussian_update_cl(g_out, g_ld, pred_list[-1], h, w))               # MAGNET.py:60-69
         if mask_out is None:
             main.wait_event(ev_pack)
-            if self.fuse_upsample and n_iter == 1 and self.downsample_ratio == 4 and m_stack.can_fuse_upsample(dev):
-                # MAGNET.py:172-173 in one launch: the mask head's last 1x1 layer soft-maxes its own logits and writes the x4-upsampled
-                # prediction; the (B, 144, h, w) mask never reaches HBM.  One prediction only: with I = 3 the per-tile epilogue (3 x 18
-                # neighbour loads at the end of a tile, nothing left to overlap them with) costs more than the separate launch that
-                # reads the mask once for all predictions (measured: C2 +1 %, shipped D = 5 / I = 3 -0.8 %)
+            if self.fuse_upsample and self.downsample_ratio == 4 and m_stack.can_fuse_upsample(dev):
+                # MAGNET.py:172-173 in one launch: behind the mask head's last 1x1 layer the workgroup soft-maxes its own logits (through
+                # LDS) and writes every iteration's x4-upsampled prediction; the (B, 144, h, w) mask never reaches HBM
                 d = torch.stack(pred_list[1:])
                 outs = torch.empty((d.shape[0], B, 2, 4 * h, 4 * w), dtype=torch.float32, device=dev)
                 m_stack.run(gin_hi[:, Dp:], gin_lo[:, Dp:], ctot, rows, wp, work.setdefault("mask", {}), upsample=(d, outs))
