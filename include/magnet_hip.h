@@ -251,6 +251,11 @@ typedef struct MagnetConvArgs {
     const float *up_depth;
     float       *up_out;
     int32_t      up_npred, up_B, up_h, up_w;
+    /* v301 — fused Gaussian update (models/MAGNET.py:60-69), for G-Net's stack (tail_cout_pad = 16): the head's two outputs of every
+     * interior position update (mu, sigma): gu_in (up_B, 2, up_h, up_w) fp32 -> gu_out (same layout; may not alias gu_in); up_B /
+     * up_h / up_w as above, out_f32 is not written.  NULL = plain tail (magnet_gaussian_update_cl then does this step). */
+    const float *gu_in;
+    float       *gu_out;
 } MagnetConvArgs;                          /* out_mode 2: one bf16 plane (round-to-nearest-even) at out_hi */
 
 MAGNET_API int magnet_conv_mfma(const MagnetConvArgs *args, void *stream);

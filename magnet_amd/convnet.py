@@ -67,6 +67,11 @@ class ConvStackMFMA:
         self._packed = None
         self._key = None
 
+    def can_fuse_gauss(self, device):
+        """True when run(..., gauss=...) is available: the reference's G-Net (3x3 + three 1x1, 2 outputs) with the fused epilogue on."""
+        self.packed(device)
+        return self._chain is not None and self.fuse_epilogue and self._chain["cout_pad"] == 16
+
     def can_fuse_upsample(self, device):
         """True when run(..., upsample=...) is available: the reference's mask head (3x3 + three 1x1, 9 * 16 outputs) with the fused
         epilogue on."""
@@ -156,11 +161,12 @@ class ConvStackMFMA:
                       False, rows, out_f32=work[key])
         return work[key]
 
-    def run(self, in_hi, in_lo, in_ld, rows, wp, work, first_addend=None, n_var=None, inv_off=None, upsample=None):
+    def run(self, in_hi, in_lo, in_ld, rows, wp, work, first_addend=None, n_var=None, inv_off=None, upsample=None, gauss=None):
         """in_hi/in_lo: bf16 views whose data_ptr is row 0, channel 0 of this stack's input; `work`: dict for cached
         hidden buffers.  Returns (fp32 tensor (rows, cout_pad_last), cout_pad_last).
         upsample = (depths (n,B,2,h,w), outs (n,B,2,4h,4w)): the mask head's stack only (144 outputs, fused tail) — the learned
-        convex upsampling runs in the tail's last layer and only `outs` is written (returns (None, 144)); see can_fuse_upsample()."""
+        convex upsampling runs in the tail's last layer and only `outs` is written (returns (None, 144)); see can_fuse_upsample().
+        gauss = (gmm_in, gmm_out): G-Net's stack only — the Gaussian update runs behind the head (returns (None, 16)); can_fuse_gauss()."""
         packs = self.packed(in_hi.device)
         if first_addend is not None:
             # first layer over the per-iteration channels only; the invariant part arrives as `first_addend`
@@ -169,7 +175,7 @@ class ConvStackMFMA:
         if self._chain is not None and self.fuse_epilogue:
             pk, ch = packs[0], self._chain
             key = ("out", rows, ch["cout_pad"])
-            if key not in work and upsample is None:
+            if key not in work and upsample is None and gauss is None:
                 work[key] = torch.empty((rows, ch["cout_pad"]), dtype=torch.float32, device=in_hi.device)
             sink = ConvStackMFMA.event_sink
             if sink is not None:
@@ -177,11 +183,11 @@ class ConvStackMFMA:
                 e0.record()
                 sink.append((e0, e1, 2.0 * rows * (pk["cout_pad"] * pk["cin"] * pk["taps"] + 128 * (256 + ch["cout_pad"])), pk["taps"]))
             lib.conv_mfma(cur_hi, cur_lo, cur_ld, pk["cin"], pk["w_hi"], pk["w_lo"], pk["bias"], pk["taps"], wp, pk["relu"], rows,
-                          out_f32=None if upsample is not None else work[key], addend=first_addend,
-                          tail=(ch["w_hi"], ch["w_lo"], ch["bias"], ch["cout_pad"]), upsample=upsample)
+                          out_f32=None if (upsample is not None or gauss is not None) else work[key], addend=first_addend,
+                          tail=(ch["w_hi"], ch["w_lo"], ch["bias"], ch["cout_pad"]), upsample=upsample, gauss=gauss)
             if sink is not None:
                 e1.record()
-            return (None if upsample is not None else work[key]), ch["cout_pad"]
+            return (None if (upsample is not None or gauss is not None) else work[key]), ch["cout_pad"]
         if self._chain is not None and self.fuse_tail and first_addend is None:
             pk = packs[0]
             key = ("hid", 0, rows, 128)

@@ -276,7 +276,7 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     if (a->out_mode < 0 || a->out_mode > 2) return fail(MAGNET_E_DIM, "magnet_conv_mfma: out_mode must be 0, 1 or 2");
     const bool tail = a->tail_w_hi != nullptr;
     if (tail) {
-        if (!a->tail_w_lo || !a->tail_bias || (!a->out_f32 && !a->up_out)) return fail(MAGNET_E_NULL, "magnet_conv_mfma: fused tail needs tail_w_lo, tail_bias and out_f32 (or up_out)");
+        if (!a->tail_w_lo || !a->tail_bias || (!a->out_f32 && !a->up_out && !a->gu_out)) return fail(MAGNET_E_NULL, "magnet_conv_mfma: fused tail needs tail_w_lo, tail_bias and out_f32 (or up_out / gu_out)");
         if (a->cout_pad != 128 || (a->tail_cout_pad != 16 && a->tail_cout_pad != 128 && a->tail_cout_pad != 144))
             return fail(MAGNET_E_DIM, "magnet_conv_mfma: fused tail needs cout_pad == 128 and tail_cout_pad in {16,128,144}");
         if (!aligned16(a->tail_w_hi) || !aligned16(a->tail_w_lo) || !aligned16(a->tail_bias) || !aligned16(a->out_f32))
@@ -342,6 +342,15 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
                         (long long)a->rows, a->wp);
         if (!aligned16(a->up_out) || ((uintptr_t)a->up_depth & 3)) return fail(MAGNET_E_ALIGN, "magnet_conv_mfma: up_out must be 16-byte aligned");
         p.up_depth = a->up_depth; p.up_out = a->up_out; p.up_npred = a->up_npred; p.up_B = a->up_B; p.up_h = a->up_h; p.up_w = a->up_w;
+    }
+    if (a->gu_out || a->gu_in) {                                     // fused Gaussian update behind G-Net's head
+        if (!a->gu_out || !a->gu_in || a->gu_in == a->gu_out) return fail(MAGNET_E_NULL, "magnet_conv_mfma: gu_in and gu_out come together and must not alias");
+        if (!tail || a->tail_cout_pad != 16 || a->up_out) return fail(MAGNET_E_DIM, "magnet_conv_mfma: the fused Gaussian update needs the 16-channel fused tail");
+        if (a->up_B <= 0 || a->up_h <= 0 || a->up_w <= 0 || a->wp != a->up_w + 2 || a->rows != (long long)a->up_B * (a->up_h + 2) * (a->up_w + 2) ||
+            a->rows >= ((long long)1 << 31))
+            return fail(MAGNET_E_DIM, "magnet_conv_mfma: up_B=%d up_h=%d up_w=%d do not describe rows=%lld, wp=%d", a->up_B, a->up_h, a->up_w,
+                        (long long)a->rows, a->wp);
+        p.gu_in = a->gu_in; p.gu_out = a->gu_out; p.up_B = a->up_B; p.up_h = a->up_h; p.up_w = a->up_w;
     }
 #ifdef MAGNET_DEV
     { static const int dev_variant = getenv("MAGNET_CONV_VARIANT") ? atoi(getenv("MAGNET_CONV_VARIANT")) : 0; p.variant = dev_variant; }   // dev A/B switch (dev build only)

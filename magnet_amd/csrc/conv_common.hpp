@@ -36,6 +36,9 @@ struct ConvParams {
     // written to out_f32.  Rows are positions of (B, up_h + 2, up_w + 2) grids (wp = up_w + 2).
     const float* up_depth; float* up_out;
     int up_npred, up_h, up_w, up_B;
+    // fused Gaussian update (tail_cout == 16 only; models/MAGNET.py:60-69): the G-Net head's two outputs (o0, o1) of an interior
+    // position update (mu, sigma) in place of the (rows, 16) fp32 write: gu_in (up_B, 2, up_h, up_w) -> gu_out, same layout
+    const float* gu_in; float* gu_out;
     int variant;                                      // dev: bit 1 = 8-wave ping-pong K loop (conv_mfma.hip, PP) instead of the default
 };
 

@@ -59,7 +59,7 @@ __device__ __forceinline__ int act_swz(int row, int slot) { return row * 256 + (
 // staging, so no barrier: the rows are wave-private).  Operands are swapped (weights = MFMA A operand): the accumulator is
 // C^T — a lane holds 4 CONSECUTIVE output channels of one row.
 // Arguments of the fused convex upsampling (ConvParams::up_*), passed by value to the row-owned last tail layer
-struct UpArgs { const float* depth; float* out; int npred, h, w, B; };
+struct UpArgs { const float* depth; float* out; int npred, h, w, B; };   // Gaussian update: depth = (mu, sigma) in, out = (mu, sigma) out, npred = -1
 
 template <int NF, bool LAST, int MT = 2, bool UP = false>
 __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, const uint16_t* __restrict__ w_lo,
@@ -338,6 +338,25 @@ __device__ __forceinline__ void tail_layer_cols(const uint16_t* __restrict__ w_h
             *reinterpret_cast<uint2*>(act_lo + off) = make_uint2(l01, l23);
         } else {
             const long long row = row0 + trow;
+            if constexpr (TAILN == 1) {
+                if (up.npred < 0) {
+                    // fused Gaussian update (models/MAGNET.py:60-69; gaussian_update_cl_kernel's arithmetic): channels 0, 1 of the head =
+                    // the first quad's lanes; interior positions only
+                    if (ch != 0 || row >= rows) return;
+                    const int wp = up.w + 2, img_rows = (up.h + 2) * wp;
+                    const int b = (int)((unsigned)row / (unsigned)img_rows);
+                    const int rem = (int)((unsigned)row - (unsigned)b * (unsigned)img_rows);
+                    const int yy = rem / wp, xx = rem - yy * wp;
+                    if (yy < 1 || yy > up.h || xx < 1 || xx > up.w) return;
+                    const size_t hw = (size_t)up.h * up.w, pp = (size_t)(yy - 1) * up.w + (xx - 1);
+                    const float mu0 = up.depth[((size_t)b * 2 + 0) * hw + pp], sg0 = up.depth[((size_t)b * 2 + 1) * hw + pp];
+                    const float mu1 = mu0 + (v[0] * sg0);
+                    const float e = (v[1] > 0.f) ? v[1] : expm1f(v[1]);
+                    up.out[((size_t)b * 2 + 0) * hw + pp] = mu1;
+                    up.out[((size_t)b * 2 + 1) * hw + pp] = ((e + 1.0f) + 1e-10f) * sg0;
+                    return;
+                }
+            }
             if (row < rows) *reinterpret_cast<float4*>(out + (size_t)row * out_ld + ch) = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
@@ -1187,7 +1206,8 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
                     }
                 }
                 tail_layer_cols<TAIL, true, CV_BM, NW>(p.tail_w_hi + 2 * 128 * 128, p.tail_w_lo + 2 * 128 * 128, p.tail_bias + 256, act_hi, act_lo,
-                                                       p.out_f32, p.tail_cout, row0, p.rows, lane, wv);
+                                                       p.out_f32, p.tail_cout, row0, p.rows, lane, wv,
+                                                       (TAIL == 1 && p.gu_out) ? UpArgs{p.gu_in, p.gu_out, -1, p.up_h, p.up_w, p.up_B} : UpArgs{nullptr, nullptr, 0, 0, 0, 0});
                 return;
             }
         }

@@ -400,6 +400,7 @@ class MagnetConvArgs(ctypes.Structure):
         ("tail_cout_pad", ctypes.c_int32),
         ("up_depth", ctypes.c_void_p), ("up_out", ctypes.c_void_p),
         ("up_npred", ctypes.c_int32), ("up_B", ctypes.c_int32), ("up_h", ctypes.c_int32), ("up_w", ctypes.c_int32),
+        ("gu_in", ctypes.c_void_p), ("gu_out", ctypes.c_void_p),
     ]
 
 
@@ -432,7 +433,7 @@ def _bf16_ptr(t, name):
 
 
 def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, out_hi=None, out_lo=None, out_f32=None,
-              addend=None, dil=0, out_ld=0, add=None, border=None, repad=0, out_bf16=None, tail=None, upsample=None):
+              addend=None, dil=0, out_ld=0, add=None, border=None, repad=0, out_bf16=None, tail=None, upsample=None, gauss=None):
     """One convolution layer on the matrix cores.  in_hi/in_lo: bf16 tensors whose data_ptr is row 0 (possibly a
     channel-offset view of a wider buffer, `in_ld` = its row pitch in elements); weights (taps, cout_pad, cin) bf16.
     F-Net extras (include/magnet_hip.h): dil (3x3 dilation), out_ld (write a channel slice: out tensors may then be
@@ -440,7 +441,9 @@ def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, 
     interior rows to a grid with border repad-1), out_bf16 = single bf16 output plane.
     tail = (w_hi, w_lo, bias, cout_pad): the stack's three 1x1 successors fused into this launch (result in out_f32).
     upsample = (depths (n,B,2,h,w) fp32, outs (n,B,2,4h,4w) fp32): with tail cout_pad 144, the learned convex upsampling runs in
-    the tail's last layer (models/MAGNET.py:15-27) and only `outs` is written."""
+    the tail's last layer (models/MAGNET.py:15-27) and only `outs` is written.
+    gauss = (gmm_in (B,2,h,w), gmm_out): with tail cout_pad 16 (G-Net's head) the Gaussian update of models/MAGNET.py:60-69 runs
+    in the tail's last layer and only `gmm_out` is written."""
     lib = _conv_protos(load())
     a = MagnetConvArgs()
     for t, n in ((in_hi, "in_hi"), (in_lo, "in_lo"), (w_hi, "w_hi"), (w_lo, "w_lo")):
@@ -460,7 +463,14 @@ def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, 
     if tail is not None:
         a.tail_w_hi, a.tail_w_lo = _bf16_ptr(tail[0], "tail w_hi"), _bf16_ptr(tail[1], "tail w_lo")
         a.tail_bias, a.tail_cout_pad = _dev(tail[2], "tail bias", torch.float32).data_ptr(), int(tail[3])
-    if upsample is not None:
+    if gauss is not None:                                 # (gmm_in (B,2,h,w), gmm_out): Gaussian update behind G-Net's 16-channel fused tail
+        gi, go = gauss
+        if tail is None or gi.dim() != 4 or gi.shape[1] != 2 or go.shape != gi.shape:
+            raise MagnetError("conv_mfma: gauss = (gmm_in (B,2,h,w), gmm_out (B,2,h,w)) with a fused tail")
+        a.gu_in, a.gu_out = _dev(gi, "gmm_in", torch.float32).data_ptr(), _dev(go, "gmm_out", torch.float32).data_ptr()
+        a.up_B, a.up_h, a.up_w = int(gi.shape[0]), int(gi.shape[2]), int(gi.shape[3])
+        a.out_mode = 1
+    elif upsample is not None:
         d, o = upsample
         if tail is None or d.dim() != 5 or d.shape[2] != 2 or tuple(o.shape) != (d.shape[0], d.shape[1], 2, 4 * d.shape[3], 4 * d.shape[4]):
             raise MagnetError("conv_mfma: upsample = (depths (n,B,2,h,w), outs (n,B,2,4h,4w)) with a fused tail")

@@ -288,6 +288,11 @@ class MAGNET(nn.Module):
                 matcher(ref_gmm=pred_list[-1], k_list=self.k_list, out=work["cost"])
                 lib.pack_split(work["cost"], gin_hi, gin_lo, ctot, 0)
             main.wait_event(ev_pack)                                                                 # x_d3 channels are in place
+            if self.fuse_upsample and g_stack.can_fuse_gauss(dev):
+                new_pred = torch.empty_like(pred_list[-1])                                           # MAGNET.py:62 + 60-69 in one launch
+                g_stack.run(gin_hi, gin_lo, ctot, rows, wp, work, first_addend=partial, n_var=D, inv_off=Dp, gauss=(pred_list[-1], new_pred))
+                pred_list.append(new_pred)
+                continue
             g_out, g_ld = g_stack.run(gin_hi, gin_lo, ctot, rows, wp, work, first_addend=partial, n_var=D, inv_off=Dp)  # MAGNET.py:62
             pred_list.append(lib.gaussian_update_cl(g_out, g_ld, pred_list[-1], h, w))               # MAGNET.py:60-69
         if mask_out is None:

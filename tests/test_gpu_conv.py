@@ -101,6 +101,30 @@ def test_mask_head_with_fused_upsampling_equals_the_two_launch_form(hip_lib, gpu
     assert (outs[0].cpu() - want).abs().max().item() <= 5e-6
 
 
+@pytest.mark.parametrize("B,h,w", [(2, 12, 16), (4, 120, 160)])
+def test_gnet_with_fused_gaussian_update_equals_the_two_launch_form(hip_lib, gpu, B, h, w):
+    """MAGNET.py:62 + 60-69 in one launch (the head's last layer updates (mu, sigma) itself) against G-Net -> (rows, 16) fp32 ->
+    magnet_gaussian_update_cl: bit-identical.  Both kernel forms (4-wave / 8-wave with a ragged last tile)."""
+    from magnet_amd import lib
+    from magnet_amd.convnet import ConvStackMFMA
+    seq = _stack(320, 2, seed=29).to(gpu)
+    st = ConvStackMFMA(seq)
+    assert st.can_fuse_gauss(gpu)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, 320, h, w, generator=g)
+    gmm = torch.cat([torch.rand(B, 1, h, w, generator=g) * 5 + 0.5, torch.rand(B, 1, h, w, generator=g) * 0.5 + 0.05], dim=1).to(gpu)
+    rows = B * (h + 2) * (w + 2)
+    hi = torch.zeros((rows, 320), dtype=torch.bfloat16, device=gpu); lo = torch.zeros_like(hi)
+    lib.pack_split(x.to(gpu), hi, lo, 320, 0)
+    o, ld = st.run(hi, lo, 320, rows, w + 2, {})
+    ref = lib.gaussian_update_cl(o, ld, gmm, h, w)
+    out = torch.full_like(gmm, float("nan"))
+    none, ld2 = st.run(hi, lo, 320, rows, w + 2, {}, gauss=(gmm, out))
+    torch.cuda.synchronize()
+    assert none is None and ld2 == 16
+    assert torch.equal(out, ref), f"max|d| = {(out - ref).abs().max().item():.3e}"
+
+
 def test_conv_stack_channel_map_odd_D(hip_lib, gpu):
     """G-Net with D = 5: cost channels [0,5), x_d3 at channel offset 8 of the 288-wide buffer."""
     seq = _stack(256 + 5, 2, seed=3)
