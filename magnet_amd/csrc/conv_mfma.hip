@@ -1396,6 +1396,11 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
     }
     // (the 8-wave ping-pong form of this loop, the default of the fused-tail kernels above, is no faster on the F-Net's plain
     // 128-wide layers: 18.93 vs 18.79 ms per 40 images)
+    // the loop-invariant x_d3 part of G-Net's first layer (fp32 partial sums, I >= 2): the fused-tail kernels' 8-wave ping-pong x
+    // register-window loop (same-box: C3 step -1 %); on the F-Net's plain 128-wide layers (split-bf16 outputs) it is equal to the
+    // 4-wave loop (18.64 - 18.72 vs 18.69 - 18.75 ms per 40 images; dev MAGNET_CONV_VARIANT=2048 forces it there)
+    if (p.cout_pad == 128 && p.tap_n == 3 && (p.out_mode == 1 || (p.variant & 2048)) && !(p.variant & (16 | 9)) && p.rows >= 256ll * 256 && !p.add_hi && !p.img_rows)
+        return launch_conv_nf<8, 2, 256, 1, 0, 512, true, 2>(p, s);
     if (p.cout_pad % 128 == 0 && p.tap_n == 3 && !(p.variant & 9) && !pp) return launch_conv_nf<8, 2, 128, 1, 0, 256, false, 2>(p, s);
     if (p.cout_pad % 128 == 0 && p.tap_n > 1 && !(p.variant & 1) && !pp) return launch_conv_nf<8, 2, 128, 1, 0, 256, false, 1>(p, s);
     if (p.cout_pad % 128 == 0 && pp) return launch_conv_nf<8, 2, 256, 1, 0, 512, true>(p, s);
