@@ -61,11 +61,10 @@ __device__ __forceinline__ int act_swz(int row, int slot) { return row * 256 + (
 // Arguments of the fused convex upsampling (ConvParams::up_*), passed by value to the row-owned last tail layer
 struct UpArgs { const float* depth; float* out; int npred, h, w, B; };   // Gaussian update: depth = (mu, sigma) in, out = (mu, sigma) out, npred = -1
 
-template <int NF, bool LAST, int MT = 2, bool UP = false>
+template <int NF, bool LAST, int MT = 2>
 __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, const uint16_t* __restrict__ w_lo,
                                            const float* __restrict__ bias, unsigned char* act_hi, unsigned char* act_lo,
-                                           float* __restrict__ out, int out_ld, long long row0, long long rows, int lane, int wv,
-                                           const UpArgs up = UpArgs{nullptr, nullptr, 0, 0, 0, 0}) {
+                                           float* __restrict__ out, int out_ld, long long row0, long long rows, int lane, int wv) {
     f32x4_t acc[NF][MT];
 #pragma unroll
     for (int n = 0; n < NF; ++n)
@@ -93,60 +92,6 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[m], acc[n][m], 0, 0, 0);
         }
-    }
-    if constexpr (UP) {
-        // ---- learned convex upsampling in the lanes (models/MAGNET.py:15-27; same arithmetic, in the same order, as upsample_cl_kernel) ----
-        // C^T accumulators: fragment n = neighbour n of the 3x3 window, this lane's 4 channels = sub-pixels (i = lane >> 4, j = 0..3) of one
-        // position: the 9 weights of a sub-pixel are 9 registers of one lane.  The (rows, 144) logits never leave the CU.
-        static_assert(NF == 9 && LAST, "the mask head's last layer: 9 neighbours x 16 sub-pixels");
-        const int wp = up.w + 2, img_rows = (up.h + 2) * wp, i = lane >> 4;
-        const size_t hw = (size_t)up.h * up.w;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const long long row = row0 + wv * (MT * 16) + m * 16 + (lane & 15);
-            const int b = (int)((unsigned)row / (unsigned)img_rows);                      // rows < 2^31 (checked by the API)
-            const int rem = (int)((unsigned)row - (unsigned)b * (unsigned)img_rows);
-            const int yy = rem / wp, xx = rem - yy * wp;
-            if (row >= rows || yy < 1 || yy > up.h || xx < 1 || xx > up.w) continue;     // border position: nothing to write
-            const int y = yy - 1, x = xx - 1;
-            float mv[9][4];
-            float mx[4] = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
-#pragma unroll
-            for (int n = 0; n < 9; ++n) {
-                const float4 b4 = *reinterpret_cast<const float4*>(bias + n * 16 + i * 4);
-                mv[n][0] = acc[n][m][0] + b4.x; mv[n][1] = acc[n][m][1] + b4.y; mv[n][2] = acc[n][m][2] + b4.z; mv[n][3] = acc[n][m][3] + b4.w;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], mv[n][r]);
-            }
-            float den[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int n = 0; n < 9; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { mv[n][r] = __expf(mv[n][r] - mx[r]); den[r] += mv[n][r]; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float inv = 1.0f / den[r];
-#pragma unroll
-                for (int n = 0; n < 9; ++n) mv[n][r] *= inv;
-            }
-            for (int pi = 0; pi < up.npred; ++pi) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const size_t plane = ((size_t)pi * up.B + b) * 2 + c;
-                    float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int n = 0; n < 9; ++n) {
-                        const int y2 = y + n / 3 - 1, x2 = x + n % 3 - 1;
-                        const float dv = (y2 >= 0 && y2 < up.h && x2 >= 0 && x2 < up.w) ? up.depth[plane * hw + (size_t)y2 * up.w + x2] : 0.f;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) a[r] += mv[n][r] * dv;
-                    }
-                    *reinterpret_cast<float4*>(up.out + (plane * up.h * 4 + (size_t)y * 4 + i) * ((size_t)up.w * 4) + (size_t)x * 4) =
-                        make_float4(a[0], a[1], a[2], a[3]);
-                }
-            }
-        }
-        return;
     }
     // all of this wave's reads of its rows are done (same wave, in-order LDS); publish the layer's output in place
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1214,13 +1159,6 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
         tail_layer<8, false>(p.tail_w_hi, p.tail_w_lo, p.tail_bias, act_hi, act_lo, nullptr, 0, row0, p.rows, lane, wv);
         tail_layer<8, false>(p.tail_w_hi + 128 * 128, p.tail_w_lo + 128 * 128, p.tail_bias + 128, act_hi, act_lo, nullptr, 0, row0,
                              p.rows, lane, wv);
-        if constexpr (TAIL == 9) {
-            if (p.up_out) {
-                tail_layer<9, true, 2, true>(p.tail_w_hi + 2 * 128 * 128, p.tail_w_lo + 2 * 128 * 128, p.tail_bias + 256, act_hi, act_lo, nullptr, 0,
-                                             row0, p.rows, lane, wv, UpArgs{p.up_depth, p.up_out, p.up_npred, p.up_h, p.up_w, p.up_B});
-                return;
-            }
-        }
         tail_layer<TAIL, true>(p.tail_w_hi + 2 * 128 * 128, p.tail_w_lo + 2 * 128 * 128, p.tail_bias + 256, act_hi, act_lo, p.out_f32,
                                p.tail_cout, row0, p.rows, lane, wv);
         return;
@@ -1347,6 +1285,7 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
                                                  // default 4-wave / 2-slot loop (5.83 vs 5.91 ms per C2 step), so it is not the default
     if (p.tail_w_hi) {                           // 3x3 (or 1x1) 128-wide layer + its three 1x1 successors in one kernel
         if (p.cout_pad != 128) return hipErrorInvalidValue;
+        if ((p.variant & 32) && (p.up_out || p.gu_out)) return hipErrorInvalidValue;   // dev: the row-owned tail has no fused update / upsampling
         if (pp) {
             if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true>(p, s);
             if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true>(p, s);

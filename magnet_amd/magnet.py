@@ -145,7 +145,8 @@ class MAGNET(nn.Module):
             raise lib.MagnetError(f"conv_backend must be 'mfma' or 'torch', got {conv_backend!r}")
         self.conv_backend = conv_backend
         self._work = {}                # cached device workspaces of the MFMA conv path, keyed by shape
-        self.fuse_upsample = True      # mask head's last layer writes the upsampled predictions itself (no (B,144,h,w) mask in HBM)
+        self.fuse_upsample = True      # the stacks' tails finish the job: G-Net's head applies the Gaussian update, the mask head
+                                       # writes the upsampled predictions itself (no (B,144,h,w) mask in HBM); False: separate launches
         self.hoist_invariant = True    # I >= 2: compute the x_d3 part of G-Net's first layer once per forward
         self._stacks = None
         # mask head on a side stream next to matcher + G-Net.  Measured on MI355X: no gain (10.15 vs 10.05 ms per C2 step) —
