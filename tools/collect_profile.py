@@ -90,7 +90,7 @@ if st:
         for r in rows[:16]:
             w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 for f in ("configs.jsonl", "ablate_C2_split.log", "ablate_C2_nchw.log", "issue_rate.txt", "gather_rate.txt", "mx_split.txt", "bench_fnet.json",
-          "fnet_layers.txt", "fvolume_bench.jsonl", "bench_end_to_end.json", "kernel_only_C2_nchw.json", "parity_stats_gpu_tests.txt"):
+          "fnet_layers.txt", "fvolume_bench.jsonl", "bench_end_to_end.json", "bench_pipeline.json", "kernel_only_C2_nchw.json", "parity_stats_gpu_tests.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f if f != "configs.jsonl" else "matcher_kernel_only_all_configs.jsonl"))
 for sdir, oname in (("stats_shipped", "bench_shipped_kernel_stats.csv"), ("fvolume_stats", "fvolume_kernel_stats.csv")):

@@ -54,6 +54,7 @@ timeout 200 python tools/bench_fnet.py --frames 8 --skip-torch --profile-layers 
 timeout 200 python tools/bench_fvolume.py > $O/fvolume_bench.jsonl 2> $O/fvolume.err
 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fvolume_stats -o s -- python tools/bench_fvolume.py --steps 5 > $O/fvolume_stats.log 2>&1
 timeout 200 python tools/bench_end_to_end.py > $O/bench_end_to_end.json 2> $O/bench_end_to_end.err
+timeout 200 python tools/bench_pipeline.py 2>/dev/null | tail -1 > $O/bench_pipeline.json
 # matcher variants (dev library) + instruction / gather microbenchmarks
 timeout 150 python tools/ablate.py C2 64 split > $O/ablate_C2_split.log 2>&1
 timeout 150 python tools/ablate.py C2 64 > $O/ablate_C2_nchw.log 2>&1
