@@ -68,9 +68,23 @@ def device_inputs(wl, B, seed, device):
                 cam_intrins=synth.make_intrinsics(wl.camera, h, w, B))
 
 
-def cpu_baseline(wl, model_cpu, iters, budget_s=15.0):
-    """Full hot-path step on the host CPU: oracle matcher (all cores, OpenMP) + torch-CPU G-Net +
-    oracle tail/upsample.  Bounded: one frame first, then as many frames as fit ~budget_s."""
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown CPU"
+
+
+def cpu_baseline(wl, model_cpu, iters, budget_s=10.0):
+    """The hot path on the host CPU: oracle matcher (OpenMP) + torch-CPU G-Net + oracle tail / upsample.
+    Bounded and reproducible: every figure is taken AFTER a warm-up call (the OpenMP team and the page cache exist) and the
+    matcher-only figures are medians of >= 5 (all cores) / 3 (batched) calls; a 1-thread matcher call and the CPU model string
+    are reported as SURVEY.md section 8d asks."""
+    import statistics
     from oracle import oracle
     cores = oracle.num_threads()
     torch.set_num_threads(cores)
@@ -78,34 +92,46 @@ def cpu_baseline(wl, model_cpu, iters, budget_s=15.0):
     inp = synth.make_inputs(wl, B=1, seed=0)
     x_d3 = torch.randn(1, 256, wl.h, wl.w, generator=torch.Generator().manual_seed(1)) * 0.5
 
+    def matcher(i, gmm, nthr):
+        return oracle.cost_volume_cw(None, gmm, k, i["ref_feat"], i["nghbr_feat"], i["nghbr_gmms"], i["nghbr_poses"],
+                                     i["is_valid"], i["cam_intrins"]["intM"], i["cam_intrins"]["unit_ray_array_2D"], 5.0,
+                                     n_threads=nthr)
+
     def one_frame():
         gmm = inp["ref_gmms"].clone()
         with torch.no_grad():
             for _ in range(iters):
-                cost = torch.from_numpy(oracle.cost_volume_cw(
-                    None, gmm, k, inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"],
-                    inp["is_valid"], inp["cam_intrins"]["intM"], inp["cam_intrins"]["unit_ray_array_2D"], 5.0))
+                cost = torch.from_numpy(matcher(inp, gmm, cores))
                 raw = model_cpu.g_net.gnet(torch.cat([cost, x_d3], dim=1))
                 gmm = torch.from_numpy(oracle.gaussian_update(raw.numpy(), gmm.numpy()))
             mask = model_cpu.mask_head(x_d3)
             oracle.upsample_depth_via_mask(gmm.numpy(), mask.numpy(), 4)
 
-    t0 = time.perf_counter(); one_frame(); t1 = time.perf_counter() - t0      # also warms up
-    n = max(1, min(64, int(budget_s / max(t1, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        one_frame()
-    dt = time.perf_counter() - t0
-    # matcher-only rate, for the kernel-level comparison
-    t0 = time.perf_counter()
-    oracle.cost_volume_cw(None, inp["ref_gmms"], k, inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"],
-                          inp["nghbr_poses"], inp["is_valid"], inp["cam_intrins"]["intM"],
-                          inp["cam_intrins"]["unit_ray_array_2D"], 5.0)
-    tm = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "ref-frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} frame(s) of {wl.name} ({wl.h}x{wl.w} grid, V={wl.V}, D={wl.D}, I={iters}), "
-                      f"{dt:.1f} s wall; oracle matcher OpenMP x{cores} + torch-CPU G-Net/mask head",
-            "matcher_only_frames_per_s": 1.0 / tm}
+    def timed(fn):
+        t0 = time.perf_counter(); fn(); return time.perf_counter() - t0
+
+    one_frame()                                              # warm-up: thread teams, allocator, page cache
+    t1 = timed(one_frame)
+    n = max(2, min(64, int(budget_s / max(t1, 1e-3))))
+    dt = timed(lambda: [one_frame() for _ in range(n)])
+    # matcher only, for the kernel-level comparison: median of 5 warmed calls on one frame (all cores) ...
+    tm = statistics.median(timed(lambda: matcher(inp, inp["ref_gmms"], cores)) for _ in range(5))
+    # ... the CPU's best case, a batch of frames in one call (the OpenMP loop runs over frame x row) ...
+    nb = 8
+    inb = synth.make_inputs(wl, B=nb, seed=0)
+    matcher(inb, inb["ref_gmms"], cores)
+    tb = statistics.median(timed(lambda: matcher(inb, inb["ref_gmms"], cores)) for _ in range(3))
+    # ... and one thread (one frame, one call after the warm-up above)
+    t_1 = timed(lambda: matcher(inp, inp["ref_gmms"], 1))
+    matcher(inp, inp["ref_gmms"], cores)                      # leave the OpenMP team size as found
+    return {"value": n / dt, "unit": "ref-frames/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "sample": f"{n} frame(s) of {wl.name} ({wl.h}x{wl.w} grid, V={wl.V}, D={wl.D}, I={iters}) after one warm-up frame, "
+                      f"{dt:.1f} s wall; oracle matcher OpenMP x{cores} + torch-CPU G-Net/mask head x{cores}; host CPU: {_cpu_model()}",
+            "matcher_only_frames_per_s": 1.0 / tm,
+            "matcher_only_batched_frames_per_s": nb / tb,
+            "matcher_only_1_thread_frames_per_s": 1.0 / t_1,
+            "matcher_only_sample": f"median of 5 warmed calls on 1 frame x{cores} threads; median of 3 warmed calls on {nb} frames "
+                                   f"x{cores} threads; 1 call on 1 frame x1 thread"}
 
 
 def live_counters(wl, B, fdt, timeout_s=90):
@@ -410,12 +436,19 @@ def main():
     torch.cuda.synchronize(); mdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step(True)
+        step(False)                                          # the contract's timed region holds the step and nothing else
     torch.cuda.synchronize()
     mine = time.perf_counter() - t0                          # this rank's own time for its K steps (before the closing barrier)
     mdist.barrier(); torch.cuda.synchronize()
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, device=device)
     per_rank = mdist.gather_floats(B * a.steps / max(mine, 1e-9), device=device)   # a straggler GPU shows here, not only in the max
+
+    # kernel times (roofline / roofline_conv): the same K steps again, back to back with the timed region, with HIP events on
+    # the launch stream around the matcher and the convolution launches (kept out of the contract's clock: ~6 events per step)
+    for _ in range(a.steps):
+        step(True)
+    torch.cuda.synchronize()
+    CostVolumeCW.event_sink = None; ConvStackMFMA.event_sink = None
 
     # steady state: the contract's K steps take ~0.2 s, before the chip has settled at its sustained clock under continuous
     # matrix-core load; run on for --sustain-s seconds (outside the contract's timed region) and report that rate too

@@ -18,7 +18,10 @@
  *
  * Conventions
  *   - All data pointers are DEVICE pointers unless the comment says HOST.  Buffers are caller-owned;
- *     the library never allocates device memory and never synchronises the device.
+ *     the library never synchronises the device and keeps no device memory between calls.  ONE exception to
+ *     "never allocates": magnet_depth_metrics / magnet_depth_metrics_crop take their B x 64 x 13 doubles of
+ *     partial sums from the stream-ordered pool (hipMallocAsync + hipFreeAsync on `stream`, inside the call);
+ *     every other entry point works in caller-provided buffers only.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
  *     asynchronous on that stream and re-entrant across streams.
  *   - Return value: 0 on success; >0 = MAGNET_E_* argument error; <0 = -(hipError_t).  Nothing is

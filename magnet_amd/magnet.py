@@ -296,6 +296,8 @@ class MAGNET(nn.Module):
                 continue
             g_out, g_ld = g_stack.run(gin_hi, gin_lo, ctot, rows, wp, work, first_addend=partial, n_var=D, inv_off=Dp)  # MAGNET.py:62
             pred_list.append(lib.gaussian_update_cl(g_out, g_ld, pred_list[-1], h, w))               # MAGNET.py:60-69
+        if len(pred_list) == 1:                               # no refinement iteration: the reference returns [] (MAGNET.py:172-173)
+            return []
         if mask_out is None:
             main.wait_event(ev_pack)
             if self.fuse_upsample and self.downsample_ratio == 4 and m_stack.can_fuse_upsample(dev):

@@ -289,7 +289,8 @@ def test_upsample(hip_lib, gpu, golden, k):
 @pytest.mark.parametrize("backend", ["mfma", "torch"])
 def test_magnet_forward_matches_reference_output(hip_lib, gpu, golden, backend):
     """G6: the reference's MAGNET.forward output (stub D-Net/F-Net, I=3, one invalid view) vs ours:
-    final-depth abs_rel delta < 1e-4 (BASELINE.json's parity bar)."""
+    final-depth abs_rel delta < 1e-6 (BASELINE.json's parity bar is 1e-4; the measured agreement is 1e-7-class, and the bar sits
+    next to it so that a systematic matcher error of 0.1 % cannot pass: tests/test_gpu_golden_r3.py has the negative control)."""
     from magnet_amd.magnet import MAGNET
     args = make_args(D=5, iters=3, dpv_h=12, dpv_w=16)
     m = MAGNET(args, d_net=StubDNet(seed=21), f_net=StubFNet(seed=22, fdim=8), conv_backend=backend)
@@ -306,7 +307,7 @@ def test_magnet_forward_matches_reference_output(hip_lib, gpu, golden, backend):
         got = p.cpu().numpy()
         ar = oracle.abs_rel(ref[:, 0], got[:, 0])
         print(f"[G6 iter {i}] abs_rel(ours vs reference mu) = {ar:.3e}; max|dmu|={np.abs(got[:,0]-ref[:,0]).max():.3e}")
-        assert ar < 1e-4
+        assert ar < 1e-6                                  # measured 7e-8 (torch convolutions) .. 2.8e-7 (matrix-core convolutions)
         np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=5e-3, atol=1e-6)
 
 
