@@ -34,6 +34,16 @@
 
 namespace magnet {
 
+// 16-byte loads through a global-address-space pointer (HIP's uint4 / float4 classes cannot be dereferenced through address_space(1))
+__device__ __forceinline__ uint4 v3_gld_u4(const __attribute__((address_space(1))) unsigned char* q) {
+    const v3_u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) v3_u32x4*>(q);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 v3_gld_f4(const __attribute__((address_space(1))) unsigned char* q) {
+    const v3_f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) v3_f32x4*>(q);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // fixed offsets inside a wave's LDS region
 constexpr int V3_CAP = 64;                         // open runs (= items) of one view group
 constexpr int V3_NPASS_DEFAULT = 2;                 // correlation passes whose loads are in flight together (registers: 8 per pass)
@@ -69,10 +79,12 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
         const unsigned xcd = bid % NUM_XCD, idx = bid / NUM_XCD;
         const unsigned start = (xcd < rn) ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
         const unsigned logical = start + idx;
-        b = p.magic_tiles ? (int)__umulhi(logical, p.magic_tiles) : (int)logical;        // magic 0 = division by 1
+        // (round 4: readfirstlane — the high multiply runs on the vector unit, and the frame's base pointers derived from b were carried
+        // as per-lane 64-bit values: one v_lshl_add_u64 per vector load instead of the scalar-base addressing mode)
+        b = __builtin_amdgcn_readfirstlane(p.magic_tiles ? (int)__umulhi(logical, p.magic_tiles) : (int)logical);        // magic 0 = division by 1
         tile = (int)(logical - (unsigned)b * (unsigned)(p.tiles_x * p.tiles_y));
     }
-    const int y = p.magic_tiles_x ? (int)__umulhi((unsigned)tile, p.magic_tiles_x) : tile;   // raster order: see cost_volume_fast64.hip's launcher
+    const int y = __builtin_amdgcn_readfirstlane(p.magic_tiles_x ? (int)__umulhi((unsigned)tile, p.magic_tiles_x) : tile);   // raster order: see cost_volume_fast64.hip's launcher
     const int tx = tile - y * p.tiles_x;
     const int yc = min(y, p.h - 1);
     const int x_base = (tx * 4 + wv) * NPX;
@@ -139,8 +151,17 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     const uint32_t tap4 = (uint32_t)tap * 4u;
     const float invV = 1.0f / (float)p.V;
     const uint32_t kmax = (uint32_t)(p.V - 1) * vstride + map_texels - 1u;                  // last quad index relative to frame b, view 0
-    const unsigned char* const src_b = reinterpret_cast<const unsigned char*>(p.src_feat) + (size_t)b * map_texels * texel_bytes;
-    const unsigned char* const gq_b = reinterpret_cast<const unsigned char*>(p.src_gmq) + (size_t)b * map_texels * 32;
+    // frame bases pinned into SGPRs and typed as GLOBAL pointers: base + zero-extended 32-bit lane offset then selects the
+    // scalar-base addressing mode of the vector loads (the 64-bit multiply above runs on the vector unit, so the compiler carried
+    // these bases as per-lane register pairs and added them with one v_lshl_add_u64 per load)
+    typedef const __attribute__((address_space(1))) unsigned char* v3_gptr;
+    auto uniform_base = [](const void* q) {
+        const unsigned long long a = (unsigned long long)q;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return (v3_gptr)(((unsigned long long)hi << 32) | lo);
+    };
+    const v3_gptr src_b = uniform_base(reinterpret_cast<const unsigned char*>(p.src_feat) + (size_t)b * map_texels * texel_bytes);
+    const v3_gptr gq_b = uniform_base(reinterpret_cast<const unsigned char*>(p.src_gmq) + (size_t)b * map_texels * 32);
     const float kappa = p.kappa;
 
     const int npix = min(NPX, p.w - x_base);                                                // pixels of the segment inside the row (may be <= 0)
@@ -176,10 +197,10 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
 #pragma unroll
                     for (int a = 0; a < NPASS; ++a) {
                         if (a > 0 && ps + IPP * a >= n) break;                            // wave-uniform: this pass holds no item
-                        const unsigned char* sp = src_b + (ent[a].x + lane_src_off);
+                        const v3_gptr sp = src_b + (ent[a].x + lane_src_off);
 #pragma unroll
                         for (int cc = 0; cc < CPL; ++cc)
-                            sv[a][cc] = (FULL || (sub + LPU * cc < nchunk)) ? *reinterpret_cast<const uint4*>(sp + cc * CSTR) : make_uint4(0, 0, 0, 0);
+                            sv[a][cc] = (FULL || (sub + LPU * cc < nchunk)) ? v3_gld_u4(sp + cc * CSTR) : make_uint4(0, 0, 0, 0);
                     }
 #pragma unroll
                     for (int a = 0; a < NPASS; ++a) {
@@ -239,9 +260,9 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
                     Wb[u] = (u < nact) ? (wx & wy) : 0ull;
                     // quad index relative to (frame b, view 0): truncation = floor inside the window (ixs, iys >= 0); garbage outside it
                     keyf[u] = __umul24(v3_cvt_u32_sat(iys), (uint32_t)Wp) + v3_cvt_u32_sat(ixs) + vt.x;
-                    const unsigned char* gp = gq_b + (min(keyf[u], kmax) << 5);          // clamped: every lane loads valid memory
-                    q0[u] = *reinterpret_cast<const float4*>(gp);
-                    q1[u] = *reinterpret_cast<const float4*>(gp + 16);
+                    const v3_gptr gp = gq_b + (min(keyf[u], kmax) << 5);                    // clamped: every lane loads valid memory
+                    q0[u] = v3_gld_f4(gp);
+                    q1[u] = v3_gld_f4(gp + 16);
                     if (GBITS) vidx[u] = vt.y;
                     __builtin_amdgcn_sched_barrier(0);
                     if (u > 0) { gate_view(u - 1); __builtin_amdgcn_sched_barrier(0); }

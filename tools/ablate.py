@@ -15,6 +15,10 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 split = len(sys.argv) > 3 and sys.argv[3] == "split"
 dev = torch.device("cuda:0")
 inp = device_inputs(wl, B, 1000, dev)
+if os.environ.get("ABLATE_SMOOTH"):                      # smooth synthetic variant (synth.make_inputs smooth=): low-passed features and (mu, sigma) maps
+    sm = synth.make_inputs(wl, B=B, seed=1000, smooth=int(os.environ["ABLATE_SMOOTH"]), round_bf16=(wl.feat_dtype == "bf16"))
+    for k_ in ("ref_feat", "nghbr_feat", "ref_gmms", "nghbr_gmms"):
+        inp[k_] = sm[k_].to(dev)
 k = depth_sampling(3, wl.D)
 out = torch.empty(B, wl.D, wl.h, wl.w, device=dev)
 ld = (wl.D + 7) // 8 * 8 + 256
@@ -24,10 +28,14 @@ fdt = wl.feat_dtype
 R2 = 0x100 << 8                                       # dev flag 0x100: the round-2 production kernels although the quad map is given
 M4, M8, NP2, NP3, NP4 = 0x2000 << 8, 0x1000 << 8, 0x4000 << 8, 0x40000 << 8, 0x80000 << 8
 VG4, VG1, M7 = 0x400000 << 8, 0x800000 << 8, 0x10000 << 8
-VARIANTS = [("production (auto) = round-3 kernel", 0), ("r3 4 views in flight (6 waves)", VG4), ("r3 1 view in flight (8 waves)", VG1), ("r3 2 views, compiled for 8 waves", M8), ("r3 3 passes in flight", NP3), ("r3 4 passes in flight", NP4), ("r3 capped at 5 workgroups per CU (LDS)", 0x100000 << 8),
-            ("r3 capped at 4 workgroups per CU (LDS)", 0x200000 << 8),
-            ("r3 without dot products (timing only)", 0x200 << 8), ("round-2 kernel (fast64)", 4 | R2), ("exact cand", 2),
-            ("production (auto), again", 0)]
+V4 = 0x8 << 8                                         # dev flag 0x8: round 4's LDS-staged / matrix-pipe experiment (cost_volume_v4.hip)
+VARIANTS = [("production (auto) = cost_volume_v3.hip", 0), ("v4 experiment (LDS-DMA staging + MFMA correlation)", V4), ("production without dot products (timing only)", 0x200 << 8),
+            ("round-2 kernel (fast64)", 4 | R2), ("exact cand", 2), ("production (auto), again", 0), ("v4 experiment, again", V4)]
+if os.environ.get("ABLATE_V4"):
+    VARIANTS = [("v4 experiment", V4), ("v4, 16 slots per round (6 workgroups / CU)", V4 | (0x1000 << 8)), ("v4 capped at 4 workgroups / CU", V4 | (0x100000 << 8)),
+                ("v4 capped at 3 workgroups / CU", V4 | (0x200000 << 8)), ("production (cost_volume_v3.hip)", 0)]
+if os.environ.get("ABLATE_SHORT"):
+    VARIANTS = [VARIANTS[0], VARIANTS[1], VARIANTS[5], VARIANTS[6]]
 for name, path in VARIANTS:
     if split and (path & 0xff) == 3:
         continue
