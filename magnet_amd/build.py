@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmagnet_hip.so")
 DEV_LIB = os.path.join(HERE, "libmagnet_hip_dev.so")      # -DMAGNET_DEV build, loaded only by tools/ (lib.use_dev_build())
-SOURCES = ["api.hip", "cost_volume.hip", "cost_volume_worklist.hip", "cost_volume_cand.hip", "cost_volume_fast.hip", "cost_volume_fast64.hip", "cost_volume_v3.hip", "cost_volume_v4.hip", "cost_volume_f_bwd.hip", "cost_volume_f_gather.hip", "conv_mfma.hip", "fnet_kernels.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "cost_volume.hip", "cost_volume_worklist.hip", "cost_volume_cand.hip", "cost_volume_fast.hip", "cost_volume_fast64.hip", "cost_volume_v3.hip", "cost_volume_v4.hip", "cost_volume_v5.hip", "cost_volume_f_bwd.hip", "cost_volume_f_gather.hip", "conv_mfma.hip", "fnet_kernels.hip", "elementwise.hip"]
 HEADERS = ["cv_common.hpp", "cv_fast_common.hpp", "cv_runs.hpp", "conv_common.hpp", "warp_math.hpp", os.path.join("..", "..", "include", "magnet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fvisibility=hidden",
@@ -41,7 +41,7 @@ def _stale(lib: str = LIB) -> bool:
 # v_pk_*_f32, which on gfx950 run at HALF the per-instruction rate of their scalar forms (tools/ubench/valu_rate.hip: 4.9 vs
 # 2.5 cycles) and need their operands copied into aligned register pairs (55 v_mov per 4 views): packing is a net loss there.
 EXTRA_FLAGS = {"cost_volume_fast.hip": ["-fno-slp-vectorize"], "cost_volume_fast64.hip": ["-fno-slp-vectorize"],
-               "cost_volume_v3.hip": ["-fno-slp-vectorize"], "cost_volume_v4.hip": ["-fno-slp-vectorize"]}
+               "cost_volume_v3.hip": ["-fno-slp-vectorize"], "cost_volume_v4.hip": ["-fno-slp-vectorize"], "cost_volume_v5.hip": ["-fno-slp-vectorize"]}
 
 
 def build(force: bool = False, verbose: bool = False, dev: bool | None = None) -> str:

@@ -365,10 +365,19 @@ hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled) 
     if ((size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets
     if (fast_lds_bytes<64>(p) > 64 * 1024 || (p.D <= 32 && fast_lds_bytes<32>(p) > 64 * 1024)) return hipSuccess;   // absurd V (D <= 32: + the reference vectors)
     if (p.src_gmq && !(p.ablate & 0x100)) {                                                  // D > 32 with the quad-form (mu, sigma) map: the round-3 kernel (dev bit 0x100: the round-2 kernels)
-        if (p.ablate & 0x8) {                                                                  // dev bit 0x8: round 4's LDS-staged / matrix-pipe experiment (cost_volume_v4.hip; measured slower: DESIGN.md 4.0)
+#ifdef MAGNET_DEV
+        // round 4's two measured experiments, dev builds only: 0x8 = quads AND texels staged in LDS by DMA, correlation on the
+        // matrix pipe (cost_volume_v4.hip: 1.24 - 1.35 ms, bound by LDS bytes per unit in flight); 0x20 = round 3's kernel with the quads
+        // prefetched one unit ahead by LDS-DMA (cost_volume_v5.hip: 1.11 ms: + 15 vector / + 30 scalar instructions per (pixel, view), 6 waves)
+        if (p.ablate & 0x8) {
             const hipError_t e4 = launch_cv_v4(p, stream, handled);
             if (e4 != hipSuccess || *handled) return e4;
         }
+        if (p.ablate & 0x20) {
+            const hipError_t e5 = launch_cv_v5(p, stream, handled);
+            if (e5 != hipSuccess || *handled) return e5;
+        }
+#endif
         const hipError_t e = launch_cv_v3(p, stream, handled);
         if (e != hipSuccess || *handled) return e;
     }

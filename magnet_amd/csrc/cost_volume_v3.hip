@@ -34,16 +34,6 @@
 
 namespace magnet {
 
-// 16-byte loads through a global-address-space pointer (HIP's uint4 / float4 classes cannot be dereferenced through address_space(1))
-__device__ __forceinline__ uint4 v3_gld_u4(const __attribute__((address_space(1))) unsigned char* q) {
-    const v3_u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) v3_u32x4*>(q);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ float4 v3_gld_f4(const __attribute__((address_space(1))) unsigned char* q) {
-    const v3_f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) v3_f32x4*>(q);
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-
 // fixed offsets inside a wave's LDS region
 constexpr int V3_CAP = 64;                         // open runs (= items) of one view group
 constexpr int V3_NPASS_DEFAULT = 2;                 // correlation passes whose loads are in flight together (registers: 8 per pass)
@@ -150,19 +140,21 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     const uint32_t lane_src_off = (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes + (uint32_t)sub * 16u;
     const uint32_t tap4 = (uint32_t)tap * 4u;
     const float invV = 1.0f / (float)p.V;
-    const uint32_t kmax = (uint32_t)(p.V - 1) * vstride + map_texels - 1u;                  // last quad index relative to frame b, view 0
     // frame bases pinned into SGPRs and typed as GLOBAL pointers: base + zero-extended 32-bit lane offset then selects the
     // scalar-base addressing mode of the vector loads (the 64-bit multiply above runs on the vector unit, so the compiler carried
     // these bases as per-lane register pairs and added them with one v_lshl_add_u64 per load)
-    typedef const __attribute__((address_space(1))) unsigned char* v3_gptr;
-    auto uniform_base = [](const void* q) {
-        const unsigned long long a = (unsigned long long)q;
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-        return (v3_gptr)(((unsigned long long)hi << 32) | lo);
-    };
+    typedef cvr_gptr v3_gptr;
+    auto uniform_base = [](const void* q) { return (v3_gptr)(unsigned long long)v4_uniform_ptr(q); };
     const v3_gptr src_b = uniform_base(reinterpret_cast<const unsigned char*>(p.src_feat) + (size_t)b * map_texels * texel_bytes);
-    const v3_gptr gq_b = uniform_base(reinterpret_cast<const unsigned char*>(p.src_gmq) + (size_t)b * map_texels * 32);
+    // quad-form (mu, sigma) map of frame b over all views, as a buffer: the hardware bounds check replaces the clamp of the quad key
+    const __amdgpu_buffer_rsrc_t rsrc_q = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)v4_uniform_ptr(reinterpret_cast<const unsigned char*>(p.src_gmq) + (size_t)b * map_texels * 32), 0,
+        (int)(((uint32_t)(p.V - 1) * vstride + map_texels) * 32u), 0x00020000);
     const float kappa = p.kappa;
+    // split output: bases of the wave's first pixel pinned into SGPRs, per pixel a 32-bit byte offset (round 4; was 64-bit per-lane math)
+    v4_gu8* const hi_base = (SPLIT || p.cost_hi) ? v4_uniform_gptr(p.cost_hi + (((size_t)b * Hp + (y + 1)) * Wp + (x_base + 1)) * (size_t)p.cost_ld) : nullptr;
+    v4_gu8* const lo_base = (SPLIT || p.cost_hi) ? v4_uniform_gptr(p.cost_lo + (((size_t)b * Hp + (y + 1)) * Wp + (x_base + 1)) * (size_t)p.cost_ld) : nullptr;
+    const uint32_t ld2 = (uint32_t)p.cost_ld * 2u;
 
     const int npix = min(NPX, p.w - x_base);                                                // pixels of the segment inside the row (may be <= 0)
     const uint32_t it_lane = wb + V3_IT + (uint32_t)upair * 8u;                               // correlation unit -> its item entry of pass 0
@@ -183,7 +175,6 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
                 const uint2 ms = v3_ld_u2(wb + V3_MS + q * 8);
                 d = __builtin_fmaf(__uint_as_float(ms.y), kj, __uint_as_float(ms.x));     // MAGNET.py:155
             }
-            d = v3_sel_f(jmask, d, __builtin_nanf(""));                                    // lane without a candidate -> out of the window below
             float acc = 0.f;
 
             // (item, tap) dot products of the n open runs listed in the item table -> the runs' slots
@@ -257,12 +248,13 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
                     fxy[u] = bx[u] * by[u];
                     const unsigned long long wx = __builtin_amdgcn_ballot_w64(__float_as_uint(ixs) < xlim);
                     const unsigned long long wy = __builtin_amdgcn_ballot_w64(__float_as_uint(iys) < ylim);
-                    Wb[u] = (u < nact) ? (wx & wy) : 0ull;
+                    Wb[u] = (u < nact) ? (wx & wy & jmask) : 0ull;                          // (jmask: lanes that hold a candidate)
                     // quad index relative to (frame b, view 0): truncation = floor inside the window (ixs, iys >= 0); garbage outside it
                     keyf[u] = __umul24(v3_cvt_u32_sat(iys), (uint32_t)Wp) + v3_cvt_u32_sat(ixs) + vt.x;
-                    const v3_gptr gp = gq_b + (min(keyf[u], kmax) << 5);                    // clamped: every lane loads valid memory
-                    q0[u] = v3_gld_f4(gp);
-                    q1[u] = v3_gld_f4(gp + 16);
+                    // bounds-checked buffer loads (round 4): the key of a lane outside the window is garbage and reads as zero; was min + global load
+                    const int qo = (int)(keyf[u] << 5);
+                    q0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, qo, 0, 0));
+                    q1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, qo + 16, 0, 0));
                     if (GBITS) vidx[u] = vt.y;
                     __builtin_amdgcn_sched_barrier(0);
                     if (u > 0) { gate_view(u - 1); __builtin_amdgcn_sched_barrier(0); }
@@ -310,11 +302,11 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
             const float cval = acc * invV;                                                // homography.py:118,120
             if (SPLIT || p.cost_hi) {
                 // split-bf16 channel-last output for the conv kernel: lanes = 64 consecutive channels of one padded-grid row
-                const size_t e0 = (((size_t)b * Hp + (y + 1)) * Wp + (x + 1)) * (size_t)p.cost_ld + (size_t)(jb * 64);   // scalar
+                const uint32_t off = (uint32_t)q * ld2 + (uint32_t)j * 2u;
                 if (j < p.D) {
                     const uint16_t hi = f32_to_bf16_rne(cval);
                     const uint16_t lo = f32_to_bf16_rne(cval - bf16_to_f32(hi));
-                    (p.cost_hi + e0)[lane] = hi; (p.cost_lo + e0)[lane] = lo;
+                    *reinterpret_cast<v4_gu16*>(hi_base + off) = hi; *reinterpret_cast<v4_gu16*>(lo_base + off) = lo;
                 }
                 continue;
             }

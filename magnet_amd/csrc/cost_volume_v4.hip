@@ -28,6 +28,8 @@
 // Arithmetic and tolerance contract: as cost_volume_v3.hip / cost_volume_fast.hip (fma-contracted geometry, one v_rcp_f32,
 // padded-map texel coordinates, fp32 view sum); the channel sum of a tap is the matrix pipe's fp32 accumulation of exact
 // bf16 x bf16 products, the bilinear combine uses the difference-form weights (fp32 rounding only: homography.py:150-152,155-159).
+// (compiled into the DEV library only: a measured experiment, not a product path)
+#ifdef MAGNET_DEV
 #include "cv_runs.hpp"
 
 namespace magnet {
@@ -42,35 +44,6 @@ constexpr int v4_cs(int ns) { return V4_QS + ns * 32; }   // per slot 32 B: {c00
 constexpr int v4_tb(int ns) { return V4_QS + ns * 64; }   // unit table [NPX x valid views] x 48 B: projection terms, view offset, (mu, sigma) of the pixel
 constexpr int V4_UNIT = 48;
 constexpr int V4_FPAD = 4096;                      // the feature descriptor starts this many bytes BEFORE the frame's first texel (see dma_feats)
-
-typedef void __attribute__((address_space(3)))* v4_lptr_t;
-#define V4_LPTR(a) reinterpret_cast<v4_lptr_t>(a)
-
-// a wave-uniform pointer the compiler could not prove uniform (64-bit multiplies run on the vector unit): pin it into SGPRs, or the
-// buffer descriptor built from it lives in VGPRs and every DMA is wrapped in a readfirstlane waterfall loop
-__device__ __forceinline__ const void* v4_uniform_ptr(const void* q) {
-    const unsigned long long a = (unsigned long long)q;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    return (const void*)(((unsigned long long)hi << 32) | lo);
-}
-
-// 32-bit population count of a 64-bit scalar mask (clang keeps __builtin_popcountll in 64 bits and then compares it on the vector unit)
-__device__ __forceinline__ int v4_popc(uint64_t m) {
-    int n;
-    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
-    return n;
-}
-
-typedef __attribute__((address_space(1))) unsigned char v4_gu8;        // global address space (an integer-built generic pointer compiles to flat_ accesses)
-typedef __attribute__((address_space(1))) uint16_t v4_gu16;
-typedef __attribute__((address_space(1))) float v4_gf32;
-__device__ __forceinline__ v4_gu8* v4_uniform_gptr(const void* q) { return (v4_gu8*)(unsigned long long)v4_uniform_ptr(q); }
-
-__device__ __forceinline__ void v4_st1_mask(uint64_t mask, uint32_t addr, uint32_t val) {
-    uint64_t save;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
-                 : "=&s"(save) : "s"(mask), "v"(addr), "v"(val) : "memory", "scc");
-}
 
 // OPT bit 0: write the gate bits (parity tests); bit 6: split-bf16 channel-last output only
 template <int OPT, int MINW, int NS>
@@ -428,3 +401,4 @@ hipError_t launch_cv_v4(const CvParams& p0, hipStream_t stream, bool* handled) {
 }
 
 }  // namespace magnet
+#endif  // MAGNET_DEV

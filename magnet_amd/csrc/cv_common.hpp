@@ -92,6 +92,7 @@ hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cv_fast64(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cv_v3(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cv_v4(const CvParams& p, hipStream_t stream, bool* handled);
+hipError_t launch_cv_v5(const CvParams& p, hipStream_t stream, bool* handled);
 hipError_t launch_cvf_bwd(const CvParams& p, const float* gout, float* grad_ref, float* grad_src, hipStream_t stream,
                           bool* handled);
 hipError_t launch_cvf_bwd_ref_only(const CvParams& p, const float* gout, float* grad_ref, hipStream_t stream, bool* handled);

@@ -74,4 +74,42 @@ __device__ __forceinline__ void v3_st2_mask(uint64_t mask, uint32_t addr, uint32
 }
 
 
+// ---- round 4: helpers shared by cost_volume_v3.hip / _v4.hip / _v5.hip --------------------------------------------------------------
+// 16-byte loads through a global-address-space pointer (HIP's uint4 / float4 classes cannot be dereferenced through address_space(1))
+typedef const __attribute__((address_space(1))) unsigned char* cvr_gptr;
+__device__ __forceinline__ uint4 v3_gld_u4(cvr_gptr q) {
+    const v3_u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) v3_u32x4*>(q);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 v3_gld_f4(cvr_gptr q) {
+    const v3_f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) v3_f32x4*>(q);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+// a wave-uniform pointer the compiler could not prove uniform (64-bit multiplies run on the vector unit): pin it into SGPRs, or a
+// buffer descriptor built from it lives in VGPRs (every use wrapped in a readfirstlane waterfall loop) and a plain vector load adds
+// it per lane (v_lshl_add_u64) instead of using the scalar-base addressing mode
+__device__ __forceinline__ const void* v4_uniform_ptr(const void* q) {
+    const unsigned long long a = (unsigned long long)q;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+typedef __attribute__((address_space(1))) unsigned char v4_gu8;        // global address space (an integer-built generic pointer compiles to flat_ accesses)
+typedef __attribute__((address_space(1))) uint16_t v4_gu16;
+typedef __attribute__((address_space(1))) float v4_gf32;
+__device__ __forceinline__ v4_gu8* v4_uniform_gptr(const void* q) { return (v4_gu8*)(unsigned long long)v4_uniform_ptr(q); }
+// 32-bit population count of a 64-bit scalar mask (clang keeps __builtin_popcountll in 64 bits and then compares it on the vector unit)
+__device__ __forceinline__ int v4_popc(uint64_t m) {
+    int n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
+    return n;
+}
+__device__ __forceinline__ void v4_st1_mask(uint64_t mask, uint32_t addr, uint32_t val) {
+    uint64_t save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(mask), "v"(addr), "v"(val) : "memory", "scc");
+}
+typedef void __attribute__((address_space(3)))* v4_lptr_t;
+#define V4_LPTR(a) reinterpret_cast<v4_lptr_t>(a)
+
+
 }  // namespace magnet

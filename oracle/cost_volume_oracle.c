@@ -116,7 +116,7 @@ ORACLE_API int magnet_oracle_cost_volume_cw(
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
-    #pragma omp parallel for collapse(2) schedule(dynamic, 4)
+    #pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int b = 0; b < B; ++b) {
         for (int y = 0; y < h; ++y) {
             const float *K = intM + (size_t)b * 9;

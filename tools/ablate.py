@@ -29,11 +29,17 @@ R2 = 0x100 << 8                                       # dev flag 0x100: the roun
 M4, M8, NP2, NP3, NP4 = 0x2000 << 8, 0x1000 << 8, 0x4000 << 8, 0x40000 << 8, 0x80000 << 8
 VG4, VG1, M7 = 0x400000 << 8, 0x800000 << 8, 0x10000 << 8
 V4 = 0x8 << 8                                         # dev flag 0x8: round 4's LDS-staged / matrix-pipe experiment (cost_volume_v4.hip)
-VARIANTS = [("production (auto) = cost_volume_v3.hip", 0), ("v4 experiment (LDS-DMA staging + MFMA correlation)", V4), ("production without dot products (timing only)", 0x200 << 8),
-            ("round-2 kernel (fast64)", 4 | R2), ("exact cand", 2), ("production (auto), again", 0), ("v4 experiment, again", V4)]
+V3 = 0                                                # production = cost_volume_v3.hip (round 4: scalar frame bases, buffer-addressed quad loads)
+V5 = 0x20 << 8                                        # dev flag 0x20: round 4's quad-prefetch experiment (cost_volume_v5.hip)
+VARIANTS = [("production (auto) = cost_volume_v3.hip", 0), ("v5 experiment (quads prefetched by LDS-DMA)", V5), ("production without dot products (timing only)", 0x200 << 8),
+            ("round-2 kernel (fast64)", 4 | R2), ("exact cand", 2), ("production (auto), again", 0), ("v5 experiment, again", V5), ("v4 experiment (LDS staging + MFMA correlation)", V4)]
 if os.environ.get("ABLATE_V4"):
     VARIANTS = [("v4 experiment", V4), ("v4, 16 slots per round (6 workgroups / CU)", V4 | (0x1000 << 8)), ("v4 capped at 4 workgroups / CU", V4 | (0x100000 << 8)),
                 ("v4 capped at 3 workgroups / CU", V4 | (0x200000 << 8)), ("production (cost_volume_v3.hip)", 0)]
+if os.environ.get("ABLATE_V3"):
+    VARIANTS = [("v3 (2 views in flight)", V3), ("v3, 4 views in flight", V3 | (0x400000 << 8)), ("v3, 4 views, compiled for 8 waves", V3 | (0x401000 << 8)),
+                ("v3, 2 views, compiled for 8 waves", V3 | (0x1000 << 8)), ("v3, 3 correlation passes in flight", V3 | (0x40000 << 8)),
+                ("v3, 4 correlation passes in flight", V3 | (0x80000 << 8)), ("v3 without dot products", V3 | (0x200 << 8)), ("v3 again", V3)]
 if os.environ.get("ABLATE_SHORT"):
     VARIANTS = [VARIANTS[0], VARIANTS[1], VARIANTS[5], VARIANTS[6]]
 for name, path in VARIANTS:
