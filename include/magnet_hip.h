@@ -41,7 +41,7 @@ extern "C" {
 
 #define MAGNET_API __attribute__((visibility("default")))
 
-#define MAGNET_HIP_VERSION 301            /* major*10000 + minor*100 + patch */
+#define MAGNET_HIP_VERSION 302            /* major*10000 + minor*100 + patch */
 
 enum {                                     /* storage dtype of channel-last feature maps */
     MAGNET_FEAT_F32  = 0,
@@ -259,9 +259,24 @@ typedef struct MagnetConvArgs {
      * up_h / up_w as above, out_f32 is not written.  NULL = plain tail (magnet_gaussian_update_cl then does this step). */
     const float *gu_in;
     float       *gu_out;
+    /* v302 — the "2-unit" operand format of the 128-wide 3x3 layers with a fused tail (taps = 9, rows >= 65536, no addend): in_hi / w_hi
+     * are FP16 planes (same shapes as the bf16 hi planes), in_lo / w_lo hold per 64-byte (row, 32-channel block) slice the 32 OCP e4m3
+     * bytes of hi / 2^e_h followed by the 32 e4m3 bytes of (x - fp16(x)) / 2^e_l, and the E8M0 exponents travel separately:
+     * in_sc [cin / 32][sc_rows] uint32 {e_h + 127, e_l + 127, 0, 0} per (block, row), w_sc [taps][cin / 32][cout_pad] uint32 likewise per
+     * (tap, block, output channel).  magnet_pack_mx writes the activation planes; magnet_amd/convnet.py prepares the weights.  The kernel
+     * runs hi*hi on the fp16 matrix instruction and lo*hi + hi*lo on the block-scaled fp8 one (x*w to ~1e-5 relative, as the bf16x3 form):
+     * 2 matrix-pipe units per product term instead of 3.  NULL / 0 = the bf16x3 format described above. */
+    const void  *in_sc, *w_sc;
+    int64_t      sc_rows;
 } MagnetConvArgs;                          /* out_mode 2: one bf16 plane (round-to-nearest-even) at out_hi */
 
 MAGNET_API int magnet_conv_mfma(const MagnetConvArgs *args, void *stream);
+
+/* fp32 NCHW (N, C, h, w) -> channels [c_off, c_off + C) of the interior of a (N, h+2, w+2, ctot) buffer in the v302 operand format of
+ * magnet_conv_mfma: out_f16 (fp16 plane), out_qr (e4m3 hi | lo bytes, 64 B per (row, 32-channel block)), out_sc [ctot / 32][sc_rows]
+ * uint32 E8M0 pairs.  C, c_off, ctot multiples of 32; h*w a multiple of 4; the border rows are not written (zero them once). */
+MAGNET_API int magnet_pack_mx(const float *nchw, void *out_f16, void *out_qr, void *out_sc, int32_t N, int32_t C, int32_t h, int32_t w,
+                              int32_t ctot, int32_t c_off, int64_t sc_rows, int64_t in_img_stride, void *stream);
 
 /* ---- the F-Net's non-GEMM layers (PSMNet feature extractor, models/submodules/F_psmnet.py:37-124; row N3) ----
  * Activations are conv_mfma's format: zero-bordered channel-last grids as two bf16 planes (hi, lo). */

@@ -23,6 +23,29 @@ def split_bf16(x: torch.Tensor):
     return hi.contiguous(), lo.contiguous()
 
 
+def mx_quant(v: torch.Tensor):
+    """Block-scaled OCP e4m3 (MX-fp8) of v (..., nblk, 32) fp32: one E8M0 exponent per block with max |v| / 2^e in [128, 256) (<= 448), e = -127
+    for an all-zero block.  Returns (bytes uint8 (..., nblk, 32), e + 127 int32 (..., nblk)).  The rule of magnet_pack_mx (conv_mfma.hip)."""
+    m = v.abs().amax(-1)
+    _, ex = torch.frexp(m)
+    e = (ex.to(torch.int32) - 8).clamp(min=-127)
+    e = torch.where(m > 0, e, torch.full_like(e, -127))
+    q = (v * torch.exp2(-e.float()).unsqueeze(-1)).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), e + 127
+
+
+def split_mx(x: torch.Tensor):
+    """x (..., K) fp32, K % 32 == 0 -> the fp16 + e4m3 operand format of magnet_conv_mfma v302: (hi (..., K) fp16, qr (..., K) int16 container of
+    the [32 hi bytes | 32 lo bytes] per 32-element block, sc (..., K / 32) int32 = E8M0(hi) | E8M0(lo) << 8)."""
+    hi = x.to(torch.float16)
+    lo = x - hi.float()
+    shp = x.shape[:-1] + (x.shape[-1] // 32, 32)
+    q, eq = mx_quant(hi.float().reshape(shp))
+    r, er = mx_quant(lo.reshape(shp))
+    qr = torch.cat([q, r], dim=-1).contiguous().view(torch.int16).reshape(x.shape)
+    return hi.contiguous(), qr, (eq | (er << 8)).to(torch.int32).contiguous()
+
+
 def _cout_pad(c):
     if c <= 16:
         return 16
@@ -126,6 +149,18 @@ class ConvStackMFMA:
         return out
 
     @torch.no_grad()
+    @torch.no_grad()
+    def packed_mx(self, device):
+        """First layer's weights in the fp16 + e4m3 operand format (conv_mfma.hip, WIN == 4 loop): (w_f16 (taps, cout_pad, cin), w_qr
+        (taps, cout_pad, cin) int16 container, w_sc (taps, cin / 32, cout_pad) int32)."""
+        pk = self.packed(device)[0]
+        key = ("mx", self._key)
+        if getattr(self, "_mx_key", None) != key:
+            w = (pk["w_hi"].float() + pk["w_lo"].float())                   # the 16-bit-mantissa weights the bf16x3 path multiplies by
+            hi, qr, sc = split_mx(w)
+            self._mx, self._mx_key = dict(w_hi=hi, w_lo=qr, w_sc=sc.permute(0, 2, 1).contiguous()), key
+        return self._mx
+
     def packed_first_split(self, device, n_var, inv_off):
         """First layer split by input channels of the (padded) input buffer: channels [0, n_var) vary per refinement
         iteration (the cost volume), channels [inv_off, cin_pad) are loop-invariant (x_d3), everything between is padding.
@@ -161,12 +196,14 @@ class ConvStackMFMA:
                       False, rows, out_f32=work[key])
         return work[key]
 
-    def run(self, in_hi, in_lo, in_ld, rows, wp, work, first_addend=None, n_var=None, inv_off=None, upsample=None, gauss=None):
+    def run(self, in_hi, in_lo, in_ld, rows, wp, work, first_addend=None, n_var=None, inv_off=None, upsample=None, gauss=None, mx=None):
         """in_hi/in_lo: bf16 views whose data_ptr is row 0, channel 0 of this stack's input; `work`: dict for cached
         hidden buffers.  Returns (fp32 tensor (rows, cout_pad_last), cout_pad_last).
         upsample = (depths (n,B,2,h,w), outs (n,B,2,4h,4w)): the mask head's stack only (144 outputs, fused tail) — the learned
         convex upsampling runs in the tail's last layer and only `outs` is written (returns (None, 144)); see can_fuse_upsample().
-        gauss = (gmm_in, gmm_out): G-Net's stack only — the Gaussian update runs behind the head (returns (None, 16)); can_fuse_gauss()."""
+        gauss = (gmm_in, gmm_out): G-Net's stack only — the Gaussian update runs behind the head (returns (None, 16)); can_fuse_gauss().
+        mx = (in_sc, sc_rows): the input planes are in the fp16 + e4m3 operand format (in_hi fp16, in_lo the e4m3 container, in_sc the
+        E8M0 plane of lib.pack_mx); fused-epilogue stacks with at least 65 536 rows only."""
         packs = self.packed(in_hi.device)
         if first_addend is not None:
             # first layer over the per-iteration channels only; the invariant part arrives as `first_addend`
@@ -182,9 +219,18 @@ class ConvStackMFMA:
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
                 sink.append((e0, e1, 2.0 * rows * (pk["cout_pad"] * pk["cin"] * pk["taps"] + 128 * (256 + ch["cout_pad"])), pk["taps"]))
-            lib.conv_mfma(cur_hi, cur_lo, cur_ld, pk["cin"], pk["w_hi"], pk["w_lo"], pk["bias"], pk["taps"], wp, pk["relu"], rows,
-                          out_f32=None if (upsample is not None or gauss is not None) else work[key], addend=first_addend,
-                          tail=(ch["w_hi"], ch["w_lo"], ch["bias"], ch["cout_pad"]), upsample=upsample, gauss=gauss)
+            if mx is not None:
+                if first_addend is not None:
+                    raise lib.MagnetError("ConvStackMFMA.run: the fp16 + e4m3 format has no addend form")
+                wm = self.packed_mx(in_hi.device)
+                lib.conv_mfma(cur_hi, cur_lo, cur_ld, pk["cin"], wm["w_hi"], wm["w_lo"], pk["bias"], pk["taps"], wp, pk["relu"], rows,
+                              out_f32=None if (upsample is not None or gauss is not None) else work[key],
+                              tail=(ch["w_hi"], ch["w_lo"], ch["bias"], ch["cout_pad"]), upsample=upsample, gauss=gauss,
+                              mx=(mx[0], wm["w_sc"], mx[1]))
+            else:
+                lib.conv_mfma(cur_hi, cur_lo, cur_ld, pk["cin"], pk["w_hi"], pk["w_lo"], pk["bias"], pk["taps"], wp, pk["relu"], rows,
+                              out_f32=None if (upsample is not None or gauss is not None) else work[key], addend=first_addend,
+                              tail=(ch["w_hi"], ch["w_lo"], ch["bias"], ch["cout_pad"]), upsample=upsample, gauss=gauss)
             if sink is not None:
                 e1.record()
             return (None if (upsample is not None or gauss is not None) else work[key]), ch["cout_pad"]

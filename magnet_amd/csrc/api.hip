@@ -333,6 +333,13 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     p.repad = a->repad;
     p.tail_w_hi = (const uint16_t*)a->tail_w_hi; p.tail_w_lo = (const uint16_t*)a->tail_w_lo; p.tail_bias = a->tail_bias;
     p.tail_cout = a->tail_cout_pad;
+    if (a->in_sc || a->w_sc) {                                       // v302: fp16 + block-scaled e4m3 operand format
+        if (!a->in_sc || !a->w_sc) return fail(MAGNET_E_NULL, "magnet_conv_mfma: in_sc and w_sc come together");
+        if (!tail || a->taps != 9 || a->dil > 1 || a->addend || a->rows < 256ll * 256 || a->sc_rows < a->rows || ((uintptr_t)a->in_sc & 3) || ((uintptr_t)a->w_sc & 3) ||
+            ((int64_t)(a->cin / 32) * a->sc_rows * 4 >= ((int64_t)1 << 31)))
+            return fail(MAGNET_E_SHAPE, "magnet_conv_mfma: the fp16 + e4m3 operand format serves the 3x3 layers with a fused tail, rows >= 65536, no addend");
+        p.in_sc = (const uint32_t*)a->in_sc; p.w_sc = (const uint32_t*)a->w_sc; p.sc_rows = a->sc_rows;
+    }
     if (a->up_out || a->up_depth) {                                  // fused convex upsampling in the tail's last layer
         if (!a->up_out || !a->up_depth) return fail(MAGNET_E_NULL, "magnet_conv_mfma: up_depth and up_out come together");
         if (!tail || a->tail_cout_pad != 144) return fail(MAGNET_E_DIM, "magnet_conv_mfma: the fused upsampling needs the 144-channel fused tail");
@@ -426,6 +433,19 @@ MAGNET_API int magnet_pack_split(const float* nchw, void* out_hi, void* out_lo, 
     hipError_t e = magnet::launch_pack_split(nchw, (uint16_t*)out_hi, (uint16_t*)out_lo, N, C, h, w, ctot, c_off,
                                              in_img_stride ? in_img_stride : (long long)C * h * w, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "magnet_pack_split launch");
+}
+
+MAGNET_API int magnet_pack_mx(const float* nchw, void* out_f16, void* out_qr, void* out_sc, int32_t N, int32_t C, int32_t h, int32_t w,
+                              int32_t ctot, int32_t c_off, int64_t sc_rows, int64_t in_img_stride, void* stream) {
+    if (!nchw || !out_f16 || !out_qr || !out_sc) return fail(MAGNET_E_NULL, "magnet_pack_mx: NULL pointer");
+    if (N <= 0 || C <= 0 || h <= 0 || w <= 0 || (C % 32) || (c_off % 32) || c_off < 0 || c_off + C > ctot || (ctot % 32) || ((h * w) % 4))
+        return fail(MAGNET_E_DIM, "magnet_pack_mx: bad dims N=%d C=%d h=%d w=%d ctot=%d c_off=%d (C, c_off, ctot multiples of 32; h*w of 4)", N, C, h, w, ctot, c_off);
+    if (sc_rows < (int64_t)N * (h + 2) * (w + 2)) return fail(MAGNET_E_DIM, "magnet_pack_mx: sc_rows smaller than N*(h+2)*(w+2)");
+    const int64_t stride = in_img_stride ? in_img_stride : (int64_t)C * h * w;
+    if (!aligned16(out_f16) || !aligned16(out_qr) || !aligned16(nchw) || (stride % 4)) return fail(MAGNET_E_ALIGN, "magnet_pack_mx: pointers not 16-byte aligned");
+    hipError_t e = magnet::launch_pack_mx(nchw, (uint16_t*)out_f16, (uint8_t*)out_qr, (uint32_t*)out_sc, N, C, h, w, ctot, c_off, sc_rows, stride,
+                                          (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "magnet_pack_mx launch");
 }
 
 MAGNET_API int magnet_gaussian_update_cl(const float* gnet_out_pad, int32_t ld, const float* gmm_in, float* gmm_out,

@@ -40,6 +40,11 @@ struct ConvParams {
     // position update (mu, sigma) in place of the (rows, 16) fp32 write: gu_in (up_B, 2, up_h, up_w) -> gu_out, same layout
     const float* gu_in; float* gu_out;
     int variant;                                      // dev: bit 1 = 8-wave ping-pong K loop (conv_mfma.hip, PP) instead of the default
+    // round 4, "2-unit" operand format of the 128-wide 3x3 layers (in_sc != nullptr): in_hi / w_hi = fp16 planes, in_lo / w_lo = per
+    // 64-byte (row, 32-channel chunk) slice the 32 e4m3 bytes of hi then the 32 e4m3 bytes of lo = x - fp16(x), each block scaled by
+    // its E8M0 exponent: in_sc [cin / 32][sc_rows] u32 {E8M0 of the hi block, E8M0 of the lo block, 0, 0}, w_sc [taps][cin / 32][cout_pad] u32
+    const uint32_t* in_sc; const uint32_t* w_sc;
+    long long sc_rows;                                // rows of one chunk plane of in_sc (>= rows)
 };
 
 struct ChainParams {
@@ -53,5 +58,7 @@ struct ChainParams {
 
 hipError_t launch_conv_mfma(const ConvParams&, hipStream_t);
 hipError_t launch_conv1x1_chain(const ChainParams&, hipStream_t);
+hipError_t launch_pack_mx(const float* in, uint16_t* out_f16, uint8_t* out_qr, uint32_t* out_sc, int N, int C, int h, int w, int ctot, int c_off,
+                          long long sc_rows, long long in_img_stride, hipStream_t s);
 
 }  // namespace magnet

@@ -32,6 +32,8 @@ namespace magnet {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
 [[maybe_unused]] constexpr int CV_BK = 32;
 constexpr int CV_ROW = 64;                            // bytes per staged row (32 bf16), unpadded
@@ -724,6 +726,343 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
         if (grp == 0) __builtin_amdgcn_s_barrier();           // balance group 1's extra barrier
         __syncthreads();                                      // nothing in flight; the ring is dead
     } else
+    if constexpr (WIN == 4 && PP) {
+        // ---- round 4: the "2-unit" operand split on the 8-wave ping-pong loop (ConvParams::in_sc != nullptr) ----
+        // x = hi + lo with hi = fp16(x): the main term hi_x * hi_w runs on v_mfma_f32_16x16x32_f16 (1 matrix-pipe unit per 32 K instead of
+        // 3 bf16 ones); the two correction terms lo_x * hi_w + hi_x * lo_w are 2^-12 of the result, so OCP e4m3 operands with one E8M0
+        // scale per (row, 32 channels) suffice: v_mfma_scale_f32_16x16x128_f8f6f4.  That instruction contracts 128 K, but its four
+        // 32-K blocks sit in different lane groups (lane = (row l & 15, group g = l >> 4): bytes 0..15 = K 16 g + t, bytes 16..31 =
+        // K 64 + 16 g + t; tools/ubench/mx_split.hip), i.e. each block can come from its own LDS row: block tx = the 32 channels of tap
+        // (ty, tx), block 3 = zeros.  ONE scaled MFMA per term and accumulator covers the three taps of a tap row, and the K loop keeps
+        // its 32-channel chunks: the "lo" plane of the activation / weight buffers holds, per 64-byte (row, chunk) slice, the 32 e4m3
+        // bytes of hi ("q") and the 32 of lo ("r"), staged by the same DMA pieces as the bf16 lo plane was.
+        // Per group (chunk, ty) and accumulator: 3 f16 MFMAs + 2 scaled MFMAs (~127 matrix-pipe cycles) instead of 9 bf16 ones (~175).
+        // Registers decide the schedule here (64 accumulators + 8-register e4m3 operands): the window is DOUBLE-buffered in LDS, so every
+        // sub-step reads only the fragments it multiplies — tx = 0: f16; tx = 1: f16 + term lo_x * hi_w; tx = 2: f16 + term hi_x * lo_w.
+        static_assert(NT == 512 && SPB == 1 && BN % RP == 0 && CV_BM % RP == 0 && B_PT == 1, "8 waves, whole DMA passes");
+        constexpr int AP = 2 * A_PT;
+        constexpr int QB_ZERO = 3 * B_BYTES + 512 * 4;                    // 16 zero bytes behind the scales: block 3 of the weight operand
+        constexpr int QB_BYTES = QB_ZERO + 16;
+        constexpr int AW_BYTES = 2 * A_BYTES + 512 * 4;                   // [f16 | qr] window + the scales of its rows [512] u32
+        unsigned char* const a_base = smem;                               // 2 x window
+        unsigned char* const b_ring = smem + 2 * AW_BYTES;                // 4 x f16 weight tile (prefetch distance 3 sub-steps)
+        unsigned char* const qb_base = b_ring + 4 * B_BYTES;              // 2 x {3 taps x qr weight tile, weight scales [512] u32, zeros}
+        const int aw = CV_BM + 2 * p.tap_sx;
+        const int ngroups = 3 * ksteps_per_tap;
+        int g_ty = 0, g_k0 = 0, bs_tap = 0, bs_k0 = 0, q_ty = 0, q_k0 = 0;
+        // buffers of the scales: activations [chunk][rows] u32 {E8M0 of q, E8M0 of r, 0, 0}; weights [tap][chunk][cout_pad] u32
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in_sc + base_row), 0,
+                                                                              (int)(((long long)(p.cin / 32 - 1) * p.sc_rows + (end_row - base_row)) * 4), flags);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_sc, 0, p.taps * (p.cin / 32) * p.cout_pad * 4, flags);
+        auto dma_a = [&](int buf) {                                       // window of group g_ty/g_k0: f16 plane, qr plane, scales
+            unsigned char* sa_hi = a_base + buf * AW_BYTES;
+            unsigned char* sa_lo = sa_hi + A_BYTES;
+            const int a_u = (((g_ty + p.tap_o0) * p.tap_sy + p.tap_o0 * p.tap_sx) * p.in_ld + g_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < A_PT; ++i) {
+                CV_BLDS(ra_hi, sa_hi + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+                CV_BLDS(ra_lo, sa_lo + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+            }
+            if (wv == 0 && st_r < aw - CV_BM) {
+                const int ax = a_v[0] + CV_BM * p.in_ld * 2;
+                CV_BLDS(ra_hi, sa_hi + CV_BM * CV_ROW, ax + a_u);
+                CV_BLDS(ra_lo, sa_lo + CV_BM * CV_ROW, ax + a_u);
+            }
+            // scales of window rows [0, 512): one dword per lane, wave w rows 64 w .. 64 w + 63 (rows past the window read as 0 or are never used)
+            const int srow = (int)(row0 - base_row) + (g_ty + p.tap_o0) * p.tap_sy + p.tap_o0 * p.tap_sx + wv * 64 + lane;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr_t)(sa_hi + 2 * A_BYTES + wv * 256), 4, (srow + (g_k0 / 32) * (int)p.sc_rows) * 4, 0, 0, 0);
+            if (++g_ty == 3) { g_ty = 0; g_k0 += CV_BK; }
+        };
+        auto dma_b = [&](int slot) {                                      // f16 weight tile of the next sub-step
+            unsigned char* sb_hi = b_ring + slot * B_BYTES;
+            const int b_u = (bs_tap * p.cout_pad * p.cin + bs_k0) * 2;
+            CV_BLDS(rb_hi, sb_hi + wave_row * CV_ROW, b_v[0] + b_u);
+            if (++bs_tap == 9) { bs_tap = 0; bs_k0 += CV_BK; }
+        };
+        auto dma_q = [&](int buf) {                                       // qr weight tiles of the three taps of group q_ty/q_k0 + their scales
+            unsigned char* qb = qb_base + buf * QB_BYTES;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const int b_u = ((q_ty * 3 + tx) * p.cout_pad * p.cin + q_k0) * 2;
+                CV_BLDS(rb_lo, qb + tx * B_BYTES + wave_row * CV_ROW, b_v[0] + b_u);
+            }
+            // scales [3][BN]: 3 * BN dwords of the 512-dword field; wave w fetches entries 64 w .. 64 w + 63 (past 3 * BN: out of range -> 0)
+            const int e = wv * 64 + lane, tx = e / BN, col = e - tx * BN;
+            const int so = e < 3 * BN ? (((q_ty * 3 + tx) * (p.cin / 32) + q_k0 / 32) * p.cout_pad + n0 + col) * 4 : 0x7ffffff0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(qb + 3 * B_BYTES + wv * 256), 4, so, 0, 0, 0);
+            if (++q_ty == 3) { q_ty = 0; q_k0 += CV_BK; }
+        };
+        // fragment addresses.  f16 window / weights: as the bf16 hi plane.  Correction operands: lane (r = lane & 15, g = lane >> 4)
+        // holds 16 bytes of block g >> 1 (tap tx = g >> 1, channels 16 (g & 1) ..) and 16 bytes of block 2 + (g >> 1) (g < 2: tap 2;
+        // g >= 2: block 3 — the weight side reads zeros, the activation side re-reads its first half: finite bytes x 0)
+        const int g4 = lane >> 4, gh = g4 >> 1, gl = g4 & 1;
+        int a_offx[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) a_offx[tx] = cv_swz(wm * (MF * 16) + frow + tx * p.tap_sx, g4);
+        int xq_off[2], xr_off[2];                                         // [half] within the qr window (slots 0, 1 = q; 2, 3 = r)
+        {
+            const int r1 = wm * (MF * 16) + frow + gh * p.tap_sx, r2 = g4 < 2 ? wm * (MF * 16) + frow + 2 * p.tap_sx : r1;
+            xq_off[0] = A_BYTES + cv_swz(r1, gl); xq_off[1] = A_BYTES + cv_swz(r2, gl);
+            xr_off[0] = A_BYTES + cv_swz(r1, 2 + gl); xr_off[1] = A_BYTES + cv_swz(r2, 2 + gl);
+        }
+        const int xs_off = 2 * A_BYTES + (wm * (MF * 16) + frow + (g4 < 3 ? g4 : 2) * p.tap_sx) * 4;   // scale of this lane's block (block 3: a valid one)
+        const int wcol = wn * (NFW * 16) + frow;
+        const int wq_off0 = gh * B_BYTES + cv_swz(wcol, gl), wr_off0 = gh * B_BYTES + cv_swz(wcol, 2 + gl);
+        // second half: lanes g < 2 tap 2; lanes g >= 2 the zero bytes (an address independent of the fragment column: the column stride is folded in)
+        const int wq_off1 = g4 < 2 ? 2 * B_BYTES + cv_swz(wcol, gl) : QB_ZERO, wr_off1 = g4 < 2 ? 2 * B_BYTES + cv_swz(wcol, 2 + gl) : QB_ZERO;
+        const int wn_str = g4 < 2 ? 16 * CV_ROW : 0;
+        const int ws_off = 3 * B_BYTES + ((g4 < 3 ? g4 : 2) * BN + wcol) * 4;
+        const bool no_corr_mma = (p.variant & 0x1000) != 0;               // dev: timing ablation (wrong results)
+        f16x8_t ah[MF], fbh[NFW];
+        i32x8_t xr[MF], xq[MF], wq[NFW], wr[NFW];                          // correction operands: e4m3 lo / hi of the window rows, hi / lo of the weights
+        int xsc[MF], wsc[NFW];
+        auto ld8 = [&](const unsigned char* p0, const unsigned char* p1) {
+            const uint4 u0 = *reinterpret_cast<const uint4*>(p0), u1 = *reinterpret_cast<const uint4*>(p1);
+            return i32x8_t{(int)u0.x, (int)u0.y, (int)u0.z, (int)u0.w, (int)u1.x, (int)u1.y, (int)u1.z, (int)u1.w};
+        };
+        auto load_f16 = [&](const unsigned char* win, int slot, int tx) {
+            const unsigned char* sb_hi = b_ring + slot * B_BYTES;
+#pragma unroll
+            for (int m = 0; m < MF; ++m) ah[m] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(win + a_offx[tx] + m * 16 * CV_ROW));
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) fbh[n] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
+        };
+        // 16 f16 MFMAs (main term of this tap) + the correction MFMAs of fragment columns [a0, a1) of term 1 (hi_w x lo_x) and [b0, b1) of
+        // term 2 (lo_w x hi_x).  Operands swapped as in cv_mma<true> (weights = A): C^T accumulators.  Scale bytes: 0 = hi (q), 1 = lo (r).
+        // The 32 correction MFMAs of a group are spread 8 / 12 / 12 over its three compute phases: a LOAD phase costs ~400 cycles + ~14 per
+        // fragment read whatever the other wave group computes, so the compute phases must be as even as the reads allow.
+        auto mfmas = [&](const int a0, const int a1, const int b0, const int b1) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int n = 0; n < NFW; ++n)
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[n], ah[m], acc[m][n], 0, 0, 0);
+            if (!no_corr_mma) {
+#pragma unroll
+                for (int n = 0; n < NFW; ++n) {
+                    if (n < a0 || n >= a1) continue;
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq[n], xr[m], acc[m][n], 0, 0, 0, wsc[n], 1, xsc[m]);
+                }
+#pragma unroll
+                for (int n = 0; n < NFW; ++n) {
+                    if (n < b0 || n >= b1) continue;
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wr[n], xq[m], acc[m][n], 0, 0, 1, wsc[n], 0, xsc[m]);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            // (an MFMA may not leave its phase: without pinning the accumulators here hipcc sank correction MFMAs behind the barrier into the
+            // next compute phase — operand registers of two phases live at once, spills, unbalanced phases)
+            static_assert(MF == 4 && NFW == 4, "the accumulator pin below lists 16 accumulators");
+            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]),
+                              "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto ld_wq = [&](const unsigned char* qb, const int n) {
+            wq[n] = ld8(qb + wq_off0 + n * 16 * CV_ROW, qb + wq_off1 + n * wn_str);
+            wsc[n] = *reinterpret_cast<const int*>(qb + ws_off + n * 16 * 4);
+        };
+        auto ld_wr = [&](const unsigned char* qb, const int n) { wr[n] = ld8(qb + wr_off0 + n * 16 * CV_ROW, qb + wr_off1 + n * wn_str); };
+#define CV_END_LOAD(N)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");                    \
+        __builtin_amdgcn_s_barrier();                                                          \
+        __builtin_amdgcn_sched_barrier(0);
+        const int grp = __builtin_amdgcn_readfirstlane(wv >> 2);
+        if (tid < 8) reinterpret_cast<uint32_t*>(qb_base + (tid >> 2) * QB_BYTES + QB_ZERO)[tid & 3] = 0u;
+        // Prefetch distances.  The compute phases are short now (tx = 0: 16 MFMAs), so an f16 weight tile is fetched THREE sub-steps
+        // ahead (4-slot ring) and the window / qr weights of group g + 1 at the first sub-step of group g.  Issue order per LOAD phase:
+        // L0: window + qr weights of g + 1, then stage 3g + 3;  L1: stage 3g + 4;  L2: stage 3g + 5.  Needed at the end of L_s: stage
+        // s + 1 (and, at L2, everything of group g + 1) — loads retire in order, so the waits count what may still be outstanding:
+        //   L0: stage 3g+2 | window, qr | stage 3g+3  -> AP + 5 (+ 2 for wave 0) + 2;   L1: the same + stage 3g+4 minus stage 3g+2 (landed);
+        //   L2: stages 3g+4, 3g+5 -> 2.
+        dma_a(0);
+        dma_q(0);
+        dma_b(0);
+        dma_b(1);
+        dma_b(2);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                  // window 0, qr weights 0 and stage 0 landed (this wave's pieces)
+        __syncthreads();
+        if (grp == 1) __builtin_amdgcn_s_barrier();                       // group 1 runs one barrier (= half a sub-step) behind group 0
+        int bslot = 0;                                                    // ring slot of the sub-step being read
+        for (int g = 0; g < ngroups; ++g) {
+            const bool lastg = g + 1 == ngroups;
+            const unsigned char* win = a_base + (g & 1) * AW_BYTES;
+            const unsigned char* qb = qb_base + (g & 1) * QB_BYTES;
+            // ---- tx = 0: main term + term 1 of columns 0, 1 ----
+            asm volatile("" ::: "memory");
+            load_f16(win, bslot, 0);
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                xr[m] = ld8(win + xr_off[0] + m * 16 * CV_ROW, win + xr_off[1] + m * 16 * CV_ROW);
+                xsc[m] = *reinterpret_cast<const int*>(win + xs_off + m * 64);
+            }
+            ld_wq(qb, 0); ld_wq(qb, 1);
+            if (!lastg) {
+                dma_a((g + 1) & 1); dma_q((g + 1) & 1); dma_b((bslot + 3) & 3);
+                if (wv == 0) { CV_END_LOAD(AP + 5 + 2 + 2) } else { CV_END_LOAD(AP + 5 + 2) }
+            } else { CV_END_LOAD(0) }
+            mfmas(0, 2, 0, 0);
+            bslot = (bslot + 1) & 3;
+            // ---- tx = 1: main term + term 1 of columns 2, 3 + term 2 of column 0 ----
+            asm volatile("" ::: "memory");
+            load_f16(win, bslot, 1);
+            ld_wq(qb, 2); ld_wq(qb, 3);
+#pragma unroll
+            for (int m = 0; m < MF; ++m) xq[m] = ld8(win + xq_off[0] + m * 16 * CV_ROW, win + xq_off[1] + m * 16 * CV_ROW);
+            ld_wr(qb, 0);
+            if (!lastg) {
+                dma_b((bslot + 3) & 3);
+                if (wv == 0) { CV_END_LOAD(AP + 5 + 2 + 2) } else { CV_END_LOAD(AP + 5 + 2) }
+            } else { CV_END_LOAD(0) }
+            mfmas(2, 4, 0, 1);
+            bslot = (bslot + 1) & 3;
+            // ---- tx = 2: main term + term 2 of columns 1, 2, 3 ----
+            asm volatile("" ::: "memory");
+            load_f16(win, bslot, 2);
+            ld_wr(qb, 1); ld_wr(qb, 2); ld_wr(qb, 3);
+            if (!lastg) { dma_b((bslot + 3) & 3); CV_END_LOAD(2) }
+            else { CV_END_LOAD(0) }
+            mfmas(0, 0, 1, 4);
+            bslot = (bslot + 1) & 3;
+        }
+#undef CV_END_LOAD
+        if (grp == 0) __builtin_amdgcn_s_barrier();                       // balance group 1's extra barrier
+        __syncthreads();                                                  // nothing in flight; the ring is dead
+    } else
+    if constexpr (WIN == 5 && PP) {
+        // ---- round 4: the ping-pong x register-window loop below with DEEPER prefetch.  Counters of the WIN == 2 loop (profiles/r4): the matrix
+        // pipe is 72 % busy and a LOAD phase waits ~700 cycles whatever it reads — the LDS-DMA round trip under load is ~1.1 us = 2 000 cycles,
+        // and a weight tile fetched two sub-steps (2 x 768 MFMA cycles) ahead has not landed.  The fused tail needs 128 KB of LDS anyway, so
+        // the K loop may use it: the window is DOUBLE-buffered (the next group's window is fetched a whole group ahead, at tx = 0) and the
+        // weight ring has FOUR slots (prefetch distance 3 sub-steps): 133 KB.
+        // ---- ping-pong x register window: 256-row tile, two wave groups half a step apart as in the PP
+        // loop below, but the LOAD phase of a sub-step is only the 8 weight-fragment reads (+ the 24 window reads once per group)
+        // and ~3.4 DMA pieces per wave, so it fits under the other group's 48 MFMAs.  Phase order per group: L_s = reads of stage
+        // s, DMA of stage s+2 (and of window g+1 at tx = 1), counted vmcnt for everything older, lgkmcnt(0), barrier; C_s = MFMAs,
+        // barrier.  RAW: a stage is read one L phase after every wave's wait for it and a barrier both groups passed; WAR: a
+        // slot is refilled in the L phase after the one whose reads of it retired before a barrier both groups passed.
+        static_assert(NT == 512 && SPB == 1 && BN % RP == 0 && CV_BM % RP == 0, "8 waves, whole DMA passes");
+        constexpr int BP = 2 * B_PT, AP = 2 * A_PT;
+        unsigned char* const a_base = smem;                                // 2 x [hi | lo] window
+        unsigned char* const b_ring = smem + 4 * A_BYTES;                  // 4 x [hi | lo] weight tile
+        const int aw = CV_BM + 2 * p.tap_sx;
+        const int ngroups = 3 * ksteps_per_tap;
+        int g_ty = 0, g_k0 = 0, bs_tap = 0, bs_k0 = 0;
+        auto dma_a = [&](int buf) {
+            unsigned char* sa_hi = a_base + buf * (2 * A_BYTES);
+            unsigned char* sa_lo = sa_hi + A_BYTES;
+            const int a_u = (((g_ty + p.tap_o0) * p.tap_sy + p.tap_o0 * p.tap_sx) * p.in_ld + g_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < A_PT; ++i) {
+                CV_BLDS(ra_hi, sa_hi + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+                CV_BLDS(ra_lo, sa_lo + (wave_row + i * RP) * CV_ROW, a_v[i] + a_u);
+            }
+            if (wv == 0 && st_r < aw - CV_BM) {
+                const int ax = a_v[0] + CV_BM * p.in_ld * 2;
+                CV_BLDS(ra_hi, sa_hi + CV_BM * CV_ROW, ax + a_u);
+                CV_BLDS(ra_lo, sa_lo + CV_BM * CV_ROW, ax + a_u);
+            }
+            if (++g_ty == 3) { g_ty = 0; g_k0 += CV_BK; }
+        };
+        auto dma_b = [&](int slot) {
+            unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
+            unsigned char* sb_lo = sb_hi + B_BYTES;
+            const int b_u = (bs_tap * p.cout_pad * p.cin + bs_k0) * 2;
+#pragma unroll
+            for (int i = 0; i < B_PT; ++i) {
+                CV_BLDS(rb_hi, sb_hi + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+                CV_BLDS(rb_lo, sb_lo + (wave_row + i * RP) * CV_ROW, b_v[i] + b_u);
+            }
+            if (++bs_tap == 9) { bs_tap = 0; bs_k0 += CV_BK; }
+        };
+        int a_offx[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) a_offx[tx] = cv_swz(wm * (MF * 16) + frow + tx * p.tap_sx, lane >> 4);
+        bf16x8_t ah[3][MF], al[3][MF], fbh[NFW], fbl[NFW];
+        auto load_b = [&](int slot) {
+            const unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
+            const unsigned char* sb_lo = sb_hi + B_BYTES;
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+                fbh[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
+                fbl[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_lo + b_off + n * 16 * CV_ROW));
+            }
+        };
+        auto mfmas = [&](const bf16x8_t (&xh)[MF], const bf16x8_t (&xl)[MF]) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int n = 0; n < NFW; ++n) {
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xl[m], fbh[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xh[m], fbl[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xh[m], fbh[n], acc[m][n]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+#define CV_END_LOAD(N)                                                                         \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");                    \
+        __builtin_amdgcn_s_barrier();
+        const int grp = __builtin_amdgcn_readfirstlane(wv >> 2);
+        // issue order per LOAD phase — L0: window g + 1, stage 3g + 3;  L1: stage 3g + 4;  L2: stage 3g + 5.  Needed at the end of L_s: stage s + 1
+        // (at L2 also the window of g + 1, for the fragment reads of the next L0).  Loads retire in order; still outstanding may be:
+        //   L0: stage 3g+2 | window | stage 3g+3;   L1: window | stage 3g+3 | stage 3g+4;   L2: stage 3g+4 | stage 3g+5.
+        dma_a(0);
+        dma_b(0);
+        dma_b(1);
+        dma_b(2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BP) : "memory");             // window 0 and stage 0 landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier (= half a sub-step) behind group 0
+        int bslot = 0;
+        for (int g = 0; g < ngroups; ++g) {
+            const bool lastg = g + 1 == ngroups;
+            const unsigned char* a_win = a_base + (g & 1) * (2 * A_BYTES);
+            // ---- tx = 0 ----
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int m = 0; m < MF; ++m) {
+                    ah[tx][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + a_offx[tx] + m * 16 * CV_ROW));
+                    al[tx][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + A_BYTES + a_offx[tx] + m * 16 * CV_ROW));
+                }
+            load_b(bslot);
+            if (!lastg) {
+                dma_a((g + 1) & 1); dma_b((bslot + 3) & 3);
+                if (wv == 0) { CV_END_LOAD(2 * BP + AP + 2) } else { CV_END_LOAD(2 * BP + AP) }
+            } else { CV_END_LOAD(0) }
+            mfmas(ah[0], al[0]);
+            bslot = (bslot + 1) & 3;
+            // ---- tx = 1 ----
+            asm volatile("" ::: "memory");
+            load_b(bslot);
+            if (!lastg) {
+                dma_b((bslot + 3) & 3);
+                if (wv == 0) { CV_END_LOAD(2 * BP + AP + 2) } else { CV_END_LOAD(2 * BP + AP) }
+            } else { CV_END_LOAD(0) }
+            mfmas(ah[1], al[1]);
+            bslot = (bslot + 1) & 3;
+            // ---- tx = 2 ----
+            asm volatile("" ::: "memory");
+            load_b(bslot);
+            if (!lastg) { dma_b((bslot + 3) & 3); CV_END_LOAD(2 * BP) }
+            else { CV_END_LOAD(0) }
+            mfmas(ah[2], al[2]);
+            bslot = (bslot + 1) & 3;
+        }
+#undef CV_END_LOAD
+        if (grp == 0) __builtin_amdgcn_s_barrier();           // balance group 1's extra barrier
+        __syncthreads();                                      // nothing in flight; the ring is dead
+    } else
     if constexpr (WIN == 2 && PP) {
         // ---- ping-pong x register window (DEFAULT for 128-wide 3x3 layers): 256-row tile, two wave groups half a step apart as in the PP
         // loop below, but the LOAD phase of a sub-step is only the 8 weight-fragment reads (+ the 24 window reads once per group)
@@ -1252,8 +1591,10 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
 
 template <int NF, int WN, int BM, int SPB, int NT = 256, bool PP = false, int WIN = 0>
 static size_t conv_lds_bytes() {
-    const size_t tiles = (WIN == 3 && PP) ? 4 * (size_t)(BM + 8) * CV_ROW + 4 * 2 * (size_t)(NF * 16) * CV_ROW
+    const size_t tiles = (WIN == 4 && PP) ? 2 * (2 * (size_t)(BM + 8) * CV_ROW + 512 * 4) + 4 * (size_t)(NF * 16) * CV_ROW + 2 * (3 * (size_t)(NF * 16) * CV_ROW + 512 * 4 + 16)
+                       : (WIN == 3 && PP) ? 4 * (size_t)(BM + 8) * CV_ROW + 4 * 2 * (size_t)(NF * 16) * CV_ROW
                        : (WIN == 1 && PP) ? 4 * (size_t)(BM + 8) * CV_ROW + 3 * 2 * (size_t)(NF * 16) * CV_ROW
+                       : (WIN == 5 && PP) ? 4 * (size_t)(BM + 8) * CV_ROW + 4 * 2 * (size_t)(NF * 16) * CV_ROW
                        : WIN == 2 ? 2 * (size_t)(BM + 8) * CV_ROW + 3 * 2 * (size_t)(NF * 16) * CV_ROW
                                   : (PP ? 3 : 2 * SPB) * (2 * (size_t)(WIN ? BM + 8 : BM) * CV_ROW + 2 * (size_t)(NF * 16) * CV_ROW);
     const size_t stage = (size_t)(NT / 64) * 16 * ((NF / WN) * 16 + 4) * 4;
@@ -1291,6 +1632,13 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
             if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true>(p, s);
             if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true>(p, s);
         }
+        if (p.in_sc) {                                          // round 4: fp16 + block-scaled e4m3 operand format (see the WIN == 4 loop)
+            if (p.tap_n != 3 || !p.w_sc || p.rows < 256ll * 256 || p.addend) return hipErrorInvalidValue;
+            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 4>(p, s);
+            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 4>(p, s);
+            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true, 4>(p, s);
+            return hipErrorInvalidValue;
+        }
         const bool win = p.tap_n > 1 && !(p.variant & 1);       // dev (MAGNET_CONV_VARIANT=1): one A stage per tap
         if (win && (p.variant & 4)) {                           // dev (MAGNET_CONV_VARIANT=4): 256-row tile, 8 waves, one workgroup per CU
             if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, false, 1>(p, s);
@@ -1312,6 +1660,11 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
         // — and not for the per-iteration launches of a hoisted first layer (fp32 addend, K = 9 x 32 .. 9 x 64): those are short K
         // loops between an exposed 128 KB addend load and the tail, where two co-resident 4-wave workgroups overlap better than one
         // 8-wave workgroup (same-box A/B: 425 vs 464 us at K = 288, 766 vs 804 us at K = 576)
+        if (win && p.tap_n == 3 && !(p.variant & (16 | 8)) && p.rows >= 256ll * 256 && !p.addend && (p.variant & 512)) {   // dev (MAGNET_CONV_VARIANT=512): round 4's deeper-prefetch loop (double-buffered window, 4-slot weight ring) — measured 4 % SLOWER (2.19 vs 2.10 ms): the LOAD phases are not waiting for the DMA
+            if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 5>(p, s);
+            if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 5>(p, s);
+            if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true, 5>(p, s);
+        }
         if (win && p.tap_n == 3 && !(p.variant & (16 | 8)) && p.rows >= 256ll * 256 && (!p.addend || (p.variant & 256))) {   // dev (MAGNET_CONV_VARIANT=256): 8-wave form for addend launches too
                                                                 // dev (MAGNET_CONV_VARIANT=16): the 4-wave register-window loop below
             if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 2>(p, s);
@@ -1592,6 +1945,80 @@ hipError_t launch_pack_split(const float* in, uint16_t* out_hi, uint16_t* out_lo
     const int bpi = (h * w + 63) / 64;
     const dim3 grid((unsigned)(N * bpi), (unsigned)((C + 63) / 64)), block(256);
     hipLaunchKernelGGL(pack_split_kernel, grid, block, 0, s, in, out_hi, out_lo, C, h, w, ctot, c_off, in_img_stride);
+    return hipGetLastError();
+}
+
+
+// ---- round 4: NCHW fp32 -> the "2-unit" operand format of the 128-wide 3x3 layers (ConvParams::in_sc) -----------------------------------
+// Per interior position (row) and 32-channel block: out_f16 = fp16(x) (64 B); out_qr = 32 e4m3 bytes of hi / 2^e_h, then 32 e4m3 bytes of
+// lo / 2^e_l with lo = x - fp16(x) (exact in fp32); out_sc [block][row] = {e_h + 127, e_l + 127, 0, 0}: E8M0 exponents with
+// max |.| / 2^e in [128, 256) (<= 448, the e4m3 maximum), 0 for an all-zero block.  Same tile / transposition as pack_split_wide_kernel;
+// one thread = one (pixel, block).
+__device__ __forceinline__ int mx_block_exp(float m) {                        // m = max |v| >= 0
+    if (!(m > 0.f)) return -127;
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xff) - 127 - 7;        // floor(log2 m) - 7 (denormal m: exponent field 0 -> -134 -> clamped)
+    return e < -127 ? -127 : e;
+}
+__global__ __launch_bounds__(256) void pack_mx_kernel(const float* __restrict__ in, uint16_t* __restrict__ out_f16, uint8_t* __restrict__ out_qr,
+                                                       uint32_t* __restrict__ out_sc, int C, int h, int w, int ctot, int c_off,
+                                                       long long sc_rows, long long in_img_stride) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * PW_S];
+    const int hw = h * w;
+    const int bpi = (hw + PW_PIX - 1) / PW_PIX;
+    const int n = blockIdx.x / bpi, p0 = (blockIdx.x % bpi) * PW_PIX, f0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, l4 = (tid & 31) * 4, cr = tid >> 5;
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = cr + 8 * k, f = f0 + c, pp = p0 + l4;
+        v[k] = (pp < hw && f < C) ? *reinterpret_cast<const float4*>(in + (size_t)n * in_img_stride + (size_t)f * hw + pp)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(&tile[pw_idx(cr + 8 * k, l4)]) = v[k];
+    __syncthreads();
+    const int q = tid & 127, blk = tid >> 7, pq = p0 + q;
+    if (pq >= hw || f0 + blk * 32 >= C) return;
+    const int y = pq / w, x = pq - y * w;
+    const size_t row = ((size_t)n * (h + 2) + (y + 1)) * (w + 2) + (x + 1);
+    float hi[32], lo[32], mh = 0.f, ml = 0.f;
+    uint32_t hw16[16];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        const float xv = tile[pw_idx(blk * 32 + c, q)];
+        const _Float16 hh = (_Float16)xv;
+        hi[c] = (float)hh; lo[c] = xv - hi[c];
+        mh = fmaxf(mh, fabsf(hi[c])); ml = fmaxf(ml, fabsf(lo[c]));
+        const uint32_t hb = (uint32_t)__builtin_bit_cast(uint16_t, hh);
+        if (c & 1) hw16[c >> 1] |= hb << 16; else hw16[c >> 1] = hb;
+    }
+    const int eh = mx_block_exp(mh), el = mx_block_exp(ml);
+    const float ih = __uint_as_float((uint32_t)(127 - eh) << 23), il = __uint_as_float((uint32_t)(127 - el) << 23);   // 2^-e (e = -127: 2^127 x 0)
+    uint32_t qw[8], rw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int a = 0, b = 0;
+        a = __builtin_amdgcn_cvt_pk_fp8_f32(hi[4 * k] * ih, hi[4 * k + 1] * ih, a, false);
+        a = __builtin_amdgcn_cvt_pk_fp8_f32(hi[4 * k + 2] * ih, hi[4 * k + 3] * ih, a, true);
+        b = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4 * k] * il, lo[4 * k + 1] * il, b, false);
+        b = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4 * k + 2] * il, lo[4 * k + 3] * il, b, true);
+        qw[k] = (uint32_t)a; rw[k] = (uint32_t)b;
+    }
+    const size_t e = row * ctot + c_off + f0 + blk * 32;
+    uint4* o16 = reinterpret_cast<uint4*>(out_f16 + e);
+    uint4* oqr = reinterpret_cast<uint4*>(out_qr + e * 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o16[k] = make_uint4(hw16[4 * k], hw16[4 * k + 1], hw16[4 * k + 2], hw16[4 * k + 3]);
+    oqr[0] = make_uint4(qw[0], qw[1], qw[2], qw[3]); oqr[1] = make_uint4(qw[4], qw[5], qw[6], qw[7]);
+    oqr[2] = make_uint4(rw[0], rw[1], rw[2], rw[3]); oqr[3] = make_uint4(rw[4], rw[5], rw[6], rw[7]);
+    out_sc[(size_t)((c_off + f0) / 32 + blk) * sc_rows + row] = (uint32_t)(eh + 127) | ((uint32_t)(el + 127) << 8);
+}
+
+hipError_t launch_pack_mx(const float* in, uint16_t* out_f16, uint8_t* out_qr, uint32_t* out_sc, int N, int C, int h, int w, int ctot, int c_off,
+                          long long sc_rows, long long in_img_stride, hipStream_t s) {
+    const int bpw = (h * w + PW_PIX - 1) / PW_PIX;
+    hipLaunchKernelGGL(pack_mx_kernel, dim3((unsigned)(N * bpw), (unsigned)((C + 63) / 64)), dim3(256), 0, s, in, out_f16, out_qr, out_sc,
+                       C, h, w, ctot, c_off, sc_rows, in_img_stride);
     return hipGetLastError();
 }
 

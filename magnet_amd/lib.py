@@ -401,10 +401,11 @@ class MagnetConvArgs(ctypes.Structure):
         ("up_depth", ctypes.c_void_p), ("up_out", ctypes.c_void_p),
         ("up_npred", ctypes.c_int32), ("up_B", ctypes.c_int32), ("up_h", ctypes.c_int32), ("up_w", ctypes.c_int32),
         ("gu_in", ctypes.c_void_p), ("gu_out", ctypes.c_void_p),
+        ("in_sc", ctypes.c_void_p), ("w_sc", ctypes.c_void_p), ("sc_rows", ctypes.c_int64),
     ]
 
 
-API_SYMBOLS = API_SYMBOLS + ("magnet_conv_mfma", "magnet_pack_split", "magnet_gaussian_update_cl",
+API_SYMBOLS = API_SYMBOLS + ("magnet_conv_mfma", "magnet_pack_split", "magnet_pack_mx", "magnet_gaussian_update_cl",
                              "magnet_upsample_depth_cl", "magnet_upsample_depth_cl_n")
 
 
@@ -416,6 +417,8 @@ def _conv_protos(lib):
     lib.magnet_conv_mfma.argtypes = [ctypes.POINTER(MagnetConvArgs), P]
     lib.magnet_pack_split.restype = ctypes.c_int
     lib.magnet_pack_split.argtypes = [P, P, P, I, I, I, I, I, I, ctypes.c_int64, P]
+    lib.magnet_pack_mx.restype = ctypes.c_int
+    lib.magnet_pack_mx.argtypes = [P, P, P, P, I, I, I, I, I, I, ctypes.c_int64, ctypes.c_int64, P]
     lib.magnet_gaussian_update_cl.restype = ctypes.c_int
     lib.magnet_gaussian_update_cl.argtypes = [P, I, P, P, I, I, I, P]
     lib.magnet_upsample_depth_cl.restype = ctypes.c_int
@@ -433,7 +436,8 @@ def _bf16_ptr(t, name):
 
 
 def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, out_hi=None, out_lo=None, out_f32=None,
-              addend=None, dil=0, out_ld=0, add=None, border=None, repad=0, out_bf16=None, tail=None, upsample=None, gauss=None):
+              addend=None, dil=0, out_ld=0, add=None, border=None, repad=0, out_bf16=None, tail=None, upsample=None, gauss=None,
+              mx=None):
     """One convolution layer on the matrix cores.  in_hi/in_lo: bf16 tensors whose data_ptr is row 0 (possibly a
     channel-offset view of a wider buffer, `in_ld` = its row pitch in elements); weights (taps, cout_pad, cin) bf16.
     F-Net extras (include/magnet_hip.h): dil (3x3 dilation), out_ld (write a channel slice: out tensors may then be
@@ -446,9 +450,23 @@ def conv_mfma(in_hi, in_lo, in_ld, cin, w_hi, w_lo, bias, taps, wp, relu, rows, 
     in the tail's last layer and only `gmm_out` is written."""
     lib = _conv_protos(load())
     a = MagnetConvArgs()
-    for t, n in ((in_hi, "in_hi"), (in_lo, "in_lo"), (w_hi, "w_hi"), (w_lo, "w_lo")):
-        if not t.is_cuda or t.dtype != torch.bfloat16:
-            raise MagnetError(f"conv_mfma: {n} must be a bf16 GPU tensor")
+    if mx is not None:
+        # mx = (in_sc, w_sc, sc_rows): the fp16 + block-scaled e4m3 operand format (include/magnet_hip.h v302): in_hi / w_hi are fp16
+        # planes, in_lo / w_lo the 2-byte-per-channel containers of the e4m3 hi | lo bytes (any 2-byte dtype), scales as int32 tensors
+        for t, n in ((in_hi, "in_hi"), (w_hi, "w_hi")):
+            if not t.is_cuda or t.dtype != torch.float16:
+                raise MagnetError(f"conv_mfma (mx): {n} must be an fp16 GPU tensor")
+        for t, n in ((in_lo, "in_lo"), (w_lo, "w_lo")):
+            if not t.is_cuda or t.element_size() != 2:
+                raise MagnetError(f"conv_mfma (mx): {n} must be a 2-byte GPU tensor (e4m3 hi | lo bytes per 32-channel block)")
+        isc, wsc, sc_rows = mx
+        if isc.dtype != torch.int32 or wsc.dtype != torch.int32 or not isc.is_cuda or not wsc.is_cuda:
+            raise MagnetError("conv_mfma (mx): scale planes must be int32 GPU tensors")
+        a.in_sc, a.w_sc, a.sc_rows = isc.data_ptr(), wsc.data_ptr(), int(sc_rows)
+    else:
+        for t, n in ((in_hi, "in_hi"), (in_lo, "in_lo"), (w_hi, "w_hi"), (w_lo, "w_lo")):
+            if not t.is_cuda or t.dtype != torch.bfloat16:
+                raise MagnetError(f"conv_mfma: {n} must be a bf16 GPU tensor")
     a.in_hi, a.in_lo, a.w_hi, a.w_lo = in_hi.data_ptr(), in_lo.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr()
     a.bias = _dev(bias, "bias", torch.float32).data_ptr()
     a.rows, a.cin, a.cout_pad, a.taps, a.wp = int(rows), int(cin), int(w_hi.shape[1]), int(taps), int(wp)
@@ -501,6 +519,23 @@ def pack_split(x_nchw, out_hi, out_lo, ctot, c_off):
     with torch.cuda.device(x_nchw.device):
         _check(lib.magnet_pack_split(x_nchw.data_ptr(), out_hi.data_ptr(), out_lo.data_ptr(), N, C, h, w, int(ctot),
                                      int(c_off), int(x_nchw.stride(0)) if N > 1 else 0, _stream(x_nchw)), "magnet_pack_split")
+
+
+def pack_mx(x_nchw, out_f16, out_qr, out_sc, ctot, c_off, sc_rows):
+    """fp32 (N,C,h,w) -> channels [c_off, c_off+C) of the interior of a padded channel-last buffer (N,h+2,w+2,ctot) in the fp16 + e4m3
+    operand format of conv_mfma(mx=...): out_f16 fp16 plane, out_qr 2-byte container plane (hi | lo e4m3 bytes per 32-channel block),
+    out_sc int32 [ctot / 32][sc_rows] E8M0 pairs."""
+    lib = _conv_protos(load())
+    if not x_nchw.is_cuda or x_nchw.dtype != torch.float32:
+        raise MagnetError("pack_mx: input must be a float32 GPU tensor")
+    N, C, h, w = x_nchw.shape
+    if x_nchw.stride()[1:] != (h * w, w, 1):
+        raise MagnetError(f"pack_mx: unsupported input strides {x_nchw.stride()}")
+    if out_f16.dtype != torch.float16 or out_qr.element_size() != 2 or out_sc.dtype != torch.int32:
+        raise MagnetError("pack_mx: out_f16 fp16, out_qr a 2-byte dtype, out_sc int32")
+    with torch.cuda.device(x_nchw.device):
+        _check(lib.magnet_pack_mx(x_nchw.data_ptr(), out_f16.data_ptr(), out_qr.data_ptr(), out_sc.data_ptr(), N, C, h, w, int(ctot),
+                                  int(c_off), int(sc_rows), int(x_nchw.stride(0)) if N > 1 else 0, _stream(x_nchw)), "magnet_pack_mx")
 
 
 def gaussian_update_cl(gnet_out_pad, ld, gmm_in, h, w, out=None):

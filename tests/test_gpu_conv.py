@@ -239,3 +239,57 @@ def test_eval_driver_runs(hip_lib, gpu, tmp_path):
     assert set(m.keys()) == set(E.M.METRIC_ORDER) and all(np.isfinite(v) for v in m.values())
     E.M.log_metrics(str(tmp_path / "test_acc.txt"), m, "synthetic")
     assert (tmp_path / "test_acc.txt").read_text().count("\n") == 4
+
+
+# ---- round 4: the fp16 + block-scaled e4m3 operand format (ABI v302; conv_mfma.hip WIN == 4 loop, magnet_pack_mx) ----------------------
+def _pack_mx_planes(x, gpu, ctot=None, c_off=0):
+    from magnet_amd import lib
+    B, C, h, w = x.shape
+    ctot = ctot or C
+    rows = B * (h + 2) * (w + 2)
+    f16 = torch.zeros((rows, ctot), dtype=torch.float16, device=gpu)
+    qr = torch.zeros((rows, ctot), dtype=torch.int16, device=gpu)
+    sc = torch.zeros((ctot // 32, rows), dtype=torch.int32, device=gpu)
+    lib.pack_mx(x.to(gpu), f16, qr, sc, ctot, c_off, rows)
+    return f16, qr, sc, rows
+
+
+def test_pack_mx_equals_the_torch_restatement(hip_lib, gpu):
+    """magnet_pack_mx against convnet.split_mx (torch: fp16 RNE, E8M0 block exponent, e4m3 RNE): every plane bit for bit."""
+    from magnet_amd.convnet import split_mx
+    g = torch.Generator().manual_seed(3)
+    B, C, h, w = 2, 96, 10, 14
+    x = torch.randn(B, C, h, w, generator=g) * torch.exp(torch.randn(B, C, 1, 1, generator=g) * 2.0)
+    x[0, :32, 2, 3] = 0.0                                              # an all-zero block
+    x[1, 40, 5, 5] = 3.0e4; x[1, 41, 5, 5] = 1.0e-7                    # fp16-range extremes inside one block
+    f16, qr, sc, rows = _pack_mx_planes(x, gpu)
+    xi = x.permute(0, 2, 3, 1).contiguous()                            # (B, h, w, C)
+    hi, q, s = split_mx(xi)
+    inner = lambda t: t.view(B, h + 2, w + 2, -1)[:, 1:-1, 1:-1].cpu()
+    assert torch.equal(inner(f16), hi)
+    assert torch.equal(inner(qr), q)
+    assert torch.equal(sc.view(C // 32, B, h + 2, w + 2)[:, :, 1:-1, 1:-1].permute(1, 2, 3, 0).cpu(), s)
+    # border rows untouched (zeros)
+    assert f16.view(B, h + 2, w + 2, C)[:, 0].abs().sum().item() == 0 and sc.view(C // 32, B, h + 2, w + 2)[:, :, :, 0].abs().sum().item() == 0
+
+
+@pytest.mark.parametrize("cin,cout", [(320, 2), (256, 144)])
+def test_conv_stack_mx_format_matches_fp32(hip_lib, gpu, cin, cout):
+    """The 2-unit operand format (fp16 main term + block-scaled e4m3 correction terms) on the chip-filling shape, against torch fp32:
+    the same bar as the bf16x3 form (2e-5 of the output scale), and against the bf16x3 kernel on the same inputs."""
+    from magnet_amd import lib
+    from magnet_amd.convnet import ConvStackMFMA
+    seq = _stack(cin, cout, seed=cin + cout + 1)
+    x = torch.randn(4, cin, 120, 160, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        ref = seq(x)
+    B, C, h, w = x.shape
+    st = ConvStackMFMA(seq.to(gpu))
+    f16, qr, sc, rows = _pack_mx_planes(x, gpu)
+    out, ld = st.run(f16, qr, C, rows, w + 2, {}, mx=(sc, rows))
+    got = out.view(B, h + 2, w + 2, ld)[:, 1:-1, 1:-1, :cout].permute(0, 3, 1, 2).contiguous().cpu()
+    seq.cpu()
+    err = (got - ref).abs().max().item(); scale = ref.abs().max().item()
+    rms = ((got - ref).double().pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt()).item()
+    print(f"[conv mx {cin}->{cout} 4x120x160] max|d|={err:.3e} max|ref|={scale:.3f} rel={err / scale:.2e} rms rel={rms:.2e}")
+    assert torch.isfinite(got).all() and err <= 2e-5 * max(1.0, scale)
