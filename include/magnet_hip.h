@@ -86,11 +86,13 @@ typedef struct MagnetCostVolumeArgs {
                                               0 = auto: the PRODUCTION matcher whenever the candidates are sampled in the kernel
                                                   (d_volume == NULL, mode 0, stats == NULL); otherwise the exact candidate-lane
                                                   kernel; the generic kernel for shapes neither takes.
-                                                  Production contract (TOLERANCE parity with homography.py:124-161): at most a 1e-5
-                                                  fraction of the consistency gates differs from the reference's; every entry none
+                                                  Production contract (TOLERANCE parity with homography.py:124-161): at most a 1e-5 x
+                                                  max(1, (max(h, w) + 1) / 161) fraction of the consistency gates differs from the
+                                                  reference's (1e-5 up to 160-wide grids; measured 1.2e-5 at the 640-wide C2L grid: both
+                                                  sides' positions carry ~ulp(max(h, w)) texels of fp32 rounding); every entry none
                                                   of whose gates differs is within 2e-5 + 2e-5|c| + eps*S of the reference, where
                                                   S = sum over open views of (|dc/dx| + |dc/dy|) is the score's slope in the sample
-                                                  position and eps = 4 ulp(max(h, w) + 1) texels: the kernel's sample position
+                                                  position and eps = 4 ulp(max(h, w) + 1) texels (6 ulp on grids wider than 512): the kernel's sample position
                                                   differs from the reference's by its normalise / unnormalise rounding (<= 1.5e-5
                                                   texel), so on features that vary strongly from texel to texel (white noise) the
                                                   plain 2e-5 + 2e-5|c| bound alone does NOT hold; on smooth features it does

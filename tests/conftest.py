@@ -27,6 +27,13 @@ def golden_r2():
 
 
 @pytest.fixture(scope="session")
+def golden_r4():
+    """Round-4 golden vector from the imported reference (tests/golden/make_golden_r4.py): BASELINE config 5 with the reference's own
+    F-Net in the loop (G15)."""
+    return np.load(os.path.join(REPO, "tests", "golden", "golden_r4.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_r3():
     """Round-3 golden vectors from the imported reference (tests/golden/make_golden_r3.py): the reference's full forward at
     D = 64, I = 3 (G13) and est_costvolume_CW on the smooth synthetic variant at the C2 / C4 shapes (G14)."""

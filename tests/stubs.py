@@ -95,3 +95,18 @@ def magnet_nll_loss(pred_list, gt_depth, gt_mask, gamma=0.8):
         var = torch.clamp(sigma * sigma, min=1e-10)
         loss = loss + gamma ** (n - i - 1) * torch.mean((mu - gt) ** 2 / (2 * var) + 0.5 * torch.log(var))
     return loss
+
+
+def c5_case():
+    """Inputs of the C5 end-to-end golden vector G15 (tests/golden/make_golden_r4.py): 480 x 640 images, V = 6, D = 64, I = 1, F = 64,
+    7-Scenes intrinsics with the loader's ray table (the reference reads the table), seeded poses; everything regenerated by the test."""
+    from magnet_amd import data, synth
+    V, D = 6, 64
+    args = make_args(D=D, iters=1, dpv_h=120, dpv_w=160, fdim=64, V=V)
+    args.FNET_architecture, args.FNET_feature_dim = "PSM-Net", 64
+    gen = torch.Generator().manual_seed(3)
+    poses = synth.make_poses("7scenes", 1, V, gen)
+    valid = torch.ones(1, V, dtype=torch.int32)
+    cam = {kk: vv[None] for kk, vv in data.cam_intrinsics_7scenes(120, 160).items() if kk != "ray_params"}
+    ref_img = procedural_images(1, 480, 640); nb = procedural_images(V, 480, 640).flip(0)
+    return args, ref_img, nb, poses, valid, cam, dict(d=0, f=5, w=4)

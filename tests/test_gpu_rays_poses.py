@@ -8,7 +8,7 @@ import torch
 from magnet_amd import data, fnet, lib, synth
 from oracle import oracle
 from tests.parity import to_dev
-from tests.stubs import StubDNet, make_args, procedural_images, seeded_fnet_state, seeded_magnet_weights
+from tests.stubs import c5_case, StubDNet, make_args, procedural_images, seeded_fnet_state, seeded_magnet_weights
 
 pytestmark = pytest.mark.gpu
 
@@ -67,32 +67,30 @@ def test_relative_poses_on_device_match_reference(hip_lib, gpu, golden):
     assert v2.cpu().tolist() == [[1, 1, 1], [0, 0, 0]] and not p2[1].any() and torch.equal(p2[0].cpu(), en[0].float())
 
 
-def test_C5_end_to_end_fnet_to_matcher(hip_lib, gpu):
-    """BASELINE config 5 leg: 480x640 images, V = 6 source views, D = 64, 7-Scenes intrinsics (rays generated in the kernel),
-    PSMNet F-Net on the matrix cores writing the matcher's layouts, production matcher, matrix-core G-Net / mask head —
-    against the same forward with the torch F-Net + pack path and the exact matcher.  (The D-Net is a seeded stand-in: it
-    needs torch.hub)"""
+def test_C5_end_to_end_fnet_to_matcher_vs_reference(hip_lib, gpu, golden_r4):
+    """BASELINE config 5 with the F-Net in the loop, against the REFERENCE's own numbers (fixture G15: models.FNET.FNET +
+    MAGNET.forward on the CPU, tests/golden/make_golden_r4.py): 480x640 images, V = 6 source views, D = 64, 7-Scenes intrinsics.
+    Ours: PSMNet F-Net on the matrix cores writing the matcher's layouts, rays generated in the kernel from 8 scalars, production
+    matcher, matrix-core G-Net / mask head with the fused update / upsampling.  (The D-Net is a seeded stand-in on both sides: it
+    needs torch.hub)  The F-Net runs split-bf16 x 3 arithmetic over 27 layers, so the bar is abs_rel 1e-4
+    (north_star), not the 1e-6 of the matcher-only fixtures; the torch-F-Net + exact-matcher forward must meet 1e-5."""
     from magnet_amd.magnet import MAGNET
-    V, D = 6, 64
-    args = make_args(D=D, iters=1, dpv_h=120, dpv_w=160, fdim=64, V=V)
-    args.FNET_architecture, args.FNET_feature_dim = "PSM-Net", 64
-    fn = fnet.FNET(args); fn.f_net = seeded_fnet_state(fnet.FNET(args).f_net, seed=5)
-    model = MAGNET(args, d_net=StubDNet(0), f_net=fn, feat_dtype="fp32").to(gpu).eval()
-    seeded_magnet_weights(model, seed=4)
-    gen = torch.Generator().manual_seed(3)
-    poses = synth.make_poses("7scenes", 1, V, gen).to(gpu)
-    valid = torch.ones(1, V, dtype=torch.int32)
+    args, ref_img, nb, poses, valid, cam_full, seeds = c5_case()
+    V = 6
+    fn = fnet.FNET(args); fn.f_net = seeded_fnet_state(fnet.FNET(args).f_net, seed=seeds["f"])
+    model = MAGNET(args, d_net=StubDNet(seeds["d"]), f_net=fn, feat_dtype="fp32").to(gpu).eval()
+    seeded_magnet_weights(model, seed=seeds["w"])
     ci = data.cam_intrinsics_7scenes(120, 160, with_table=False)
     lean = {"intM": ci["intM"][None], "ray_params": ci["ray_params"][None]}
-    full = {kk: vv[None] for kk, vv in data.cam_intrinsics_7scenes(120, 160).items() if kk != "ray_params"}
-    ref_img = procedural_images(1, 480, 640).to(gpu); nb = procedural_images(V, 480, 640).flip(0).to(gpu)
-    outs = {}
-    for name, mfma_fnet, path, cam in (("production", True, 0, lean), ("reference-ish", False, 2, full)):
+    ref_sub, ref_sum = golden_r4["G15_pred_sub"], golden_r4["G15_pred_sum"]
+    for name, mfma_fnet, path, cam, bar in (("production", True, 0, lean, 1e-4), ("torch F-Net + exact matcher", False, 2, cam_full, 1e-5)):
         model.fnet_mfma, model.matcher_path = mfma_fnet, path
         with torch.no_grad():
-            outs[name] = model(ref_img, nb, poses, valid, cam, mode="test")
-    a, b = outs["production"][-1][:, 0].cpu(), outs["reference-ish"][-1][:, 0].cpu()
-    assert tuple(a.shape) == (1, 480, 640) and torch.isfinite(a).all()
-    rel = ((a - b).abs() / b.abs().clamp_min(1e-3)).mean().item()
-    print(f"C5 end to end (F-Net MFMA + production matcher + in-kernel rays) vs (torch F-Net + exact matcher + table): abs_rel = {rel:.2e}")
-    assert rel < 1e-4
+            out = model(ref_img.to(gpu), nb.to(gpu), poses.to(gpu), valid, cam, mode="test")
+        got = out[-1].cpu().numpy()
+        assert got.shape == (1, 2, 480, 640) and np.isfinite(got).all()
+        sub = got[:, :, ::8, ::8]
+        ar = oracle.abs_rel(ref_sub[:, 0], sub[:, 0])
+        print(f"C5 end to end, {name} vs the reference's FNET + MAGNET.forward: abs_rel = {ar:.2e}; max rel dsigma = {np.abs(sub[:, 1] / ref_sub[:, 1] - 1).max():.2e}")
+        assert ar < bar
+        np.testing.assert_allclose(got.astype(np.float64).sum(), ref_sum[0], rtol=1e-3)

@@ -1,4 +1,3 @@
-O=gpurun_out/r4n; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_conv.py -x -q -m gpu 2>&1 | tail -3 | tee $O/conv_tests.log
-timeout 300 python tools/bench_conv_mx.py 64 2>/dev/null | tee $O/bench_conv.log
-echo "== round-3 loop (dev variant 512)"; CONV_DEV_LIB=1 MAGNET_CONV_VARIANT=512 timeout 300 python tools/bench_conv_mx.py 64 2>/dev/null | tee -a $O/bench_conv.log
+O=gpurun_out/r4o; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_fast_matcher.py tests/test_gpu_rays_poses.py -x -q -m gpu -s -k "full_resolution or large_batch or oracle_forward or C5_end" > $O/new_parity.log 2>&1; echo "rc=$?" >> $O/new_parity.log
+grep -v "^\[parity" $O/new_parity.log | tail -12; grep "full grid\|B = 4200" $O/new_parity.log | cut -c1-330
