@@ -252,6 +252,13 @@ def dry_run(a, rank, world):
     torch.manual_seed(1234 + rank)
     net = GNET(ch_in=256 + wl.D)
     bcast_bytes = mdist.broadcast_module_(net, src=0)
+    fnet_bytes = 0
+    if a.with_fnet:                                          # the shared F-Net weights north_star names: their own flat bucket(s)
+        from types import SimpleNamespace
+        from magnet_amd import fnet as mfnet
+        fnet_bytes = mdist.broadcast_module_(mfnet.FNET(SimpleNamespace(FNET_architecture="PSM-Net", FNET_feature_dim=wl.F)), src=0)
+    cpus = mdist.pin_to_cpu_slice(rank, world)
+    n_cpus = mdist.gather_floats(float(len(cpus)))
     B = a.frames or 4
     lo, hi = mdist.shard_range(world * B, rank, world)
     mdist.barrier()
@@ -270,7 +277,8 @@ def dry_run(a, rank, world):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": wl.name, "frames_per_step_all_ranks": int(frames),
                                      "parallelism": f"frames sharded over {world} rank(s); one weight broadcast ({bcast_bytes} B)"},
-                          "weight_broadcast_bytes": bcast_bytes}))
+                          "weight_broadcast_bytes": bcast_bytes, "fnet_weight_broadcast_bytes": fnet_bytes,
+                          "cpus_per_rank": [int(v) for v in n_cpus]}))
     mdist.barrier()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
@@ -328,6 +336,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
+    cpus = mdist.pin_to_cpu_slice(local, world)               # one node: a contiguous CPU slice per rank (MAGNET_BENCH_AFFINITY=0: off)
 
     from magnet_amd import build as mbuild, lib
     if a.dev_lib:
@@ -358,6 +367,7 @@ def main():
     model.fuse_upsample = not a.no_fuse_upsample
     bcast_bytes = mdist.broadcast_module_(model, src=0)   # the one RCCL collective (weights), xGMI
 
+    fnet_bcast_bytes = 0
     inp = device_inputs(wl, B, seed=1000 + rank, device=device)
     k_list = model.k_list
     ev_pairs = []
@@ -376,7 +386,7 @@ def main():
                 return self.gmms, self.x_d3
         fa = make_args(wl, iters); fa.FNET_architecture = "PSM-Net"
         model.f_net = mfnet.FNET(fa).to(device).eval()
-        mdist.broadcast_module_(model.f_net, src=0)
+        fnet_bcast_bytes = mdist.broadcast_module_(model.f_net, src=0)   # the shared F-Net weights (13.4 MB): their own flat bucket(s)
         model.d_net = _ResidentDNet(torch.cat([inp["ref_gmms"], inp["nghbr_gmms"]], dim=0),
                                     inp["x_d3"])          # the forward keeps x_d3[:B] only (MAGNET.py:139)
         model.fnet_mfma = True
@@ -535,7 +545,8 @@ def main():
             "sustained_frames_per_s": sustained,
             "ms_per_step_inputs_in_kernel_layouts": packed_ms,
             "frames_per_s_inputs_in_kernel_layouts": (world * B / (packed_ms * 1e-3)) if packed_ms else None,
-            "weight_broadcast_bytes": bcast_bytes,
+            "weight_broadcast_bytes": bcast_bytes, "fnet_weight_broadcast_bytes": fnet_bcast_bytes,
+            "cpus_per_rank": len(cpus),
             "per_rank_frames_per_s": per_rank,
             "per_rank_min_max": [min(per_rank), max(per_rank)],
         }

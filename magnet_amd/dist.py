@@ -38,6 +38,32 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
+def cpu_slice(local_rank: int, local_world: int, cpus=None):
+    """The CPUs rank `local_rank` of `local_world` ranks on this node should run on: a contiguous, balanced slice of the CPUs the
+    process may use (contiguous CPU ids share a socket / NUMA node on the hosts this targets, and GPU i hangs off the socket that
+    holds slice i of 8 on the 8-GPU MI355X nodes).  With fewer CPUs than ranks every rank keeps the full set."""
+    cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
+    if local_world <= 1 or len(cpus) < local_world:
+        return cpus
+    lo, hi = shard_range(len(cpus), local_rank, local_world)
+    return cpus[lo:hi]
+
+
+def pin_to_cpu_slice(local_rank: int, local_world: int) -> list:
+    """Pin this process (host-side input generation, launch thread, torch's intra-op pool) to its CPU slice, so that 8 ranks neither
+    migrate across sockets nor oversubscribe each other's cores.  MAGNET_BENCH_AFFINITY=0 leaves the affinity alone.  Returns the
+    CPUs in effect."""
+    if os.environ.get("MAGNET_BENCH_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    mine = cpu_slice(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), torch.get_num_threads())))
+    except OSError:
+        pass
+    return sorted(os.sched_getaffinity(0))
+
+
 def shard_range(n_items: int, rank: int, world: int):
     """Contiguous, balanced [lo, hi) range of reference frames owned by `rank`."""
     base, rem = divmod(n_items, world)

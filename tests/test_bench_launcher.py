@@ -62,3 +62,34 @@ def test_bench_under_torchrun_env_does_not_respawn():
     d = _run(["--gpus", "1", "--dry-run", "--steps", "2"],
              env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
     assert d["n_gpus"] == 1
+
+
+def test_bench_world_size_8_dry_run_with_fnet_bucket():
+    """The launch the driver's scaling run makes, at its largest size: 8 ranks (gloo, no kernels), one port, 8 x (stdout + stderr)
+    pumps; every frame owned once; the G-Net bucket and — with --with-fnet — the F-Net bucket (the shared weights north_star names)
+    are broadcast and their sizes reported; every rank is pinned to its own CPU slice (when there are at least 8 CPUs)."""
+    d = _run(["--gpus", "8", "--dry-run", "--steps", "2", "--frames", "3", "--with-fnet"])
+    assert d["n_gpus"] == 8 and d["config"]["frames_per_step_all_ranks"] == 24
+    assert len(d["per_rank_frames_per_s"]) == 8 and all(v > 0 for v in d["per_rank_frames_per_s"])
+    assert d["weight_broadcast_bytes"] == (9 * (256 + 64) * 128 + 128 + 2 * (128 * 128 + 128) + 2 * 128 + 2) * 4
+    assert d["fnet_weight_broadcast_bytes"] == 13409632                  # PSMNet: 3.34 M parameters + BatchNorm buffers
+    ncpu = len(os.sched_getaffinity(0))
+    assert len(d["cpus_per_rank"]) == 8
+    if ncpu >= 8:
+        assert sum(d["cpus_per_rank"]) == ncpu and max(d["cpus_per_rank"]) - min(d["cpus_per_rank"]) <= 1
+
+
+def test_dead_rank_at_world_size_8():
+    import time
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e["MAGNET_BENCH_FAIL_RANK"] = "5"
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2"],
+                         env=e, capture_output=True, text=True, timeout=120)
+    dt = time.monotonic() - t0
+    assert out.returncode == 3, (out.returncode, out.stderr[-1500:])
+    assert dt < 10.0 + 25.0, f"launcher took {dt:.1f} s to give up"      # 8 python + torch start-ups on top of the 10 s bound
+    assert "[bench launcher] rank 5 exited with 3" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -88,3 +88,13 @@ def test_metrics_from_sums_and_log_format(tmp_path):
     assert len(lines[2].split()) == 12 and lines[2].split()[0] == "0.2500"
     r = M.RunningAverageDict(); r.update({"a": 1.0}); r.update({"a": 3.0})
     assert r.get_value()["a"] == 2.0
+
+
+def test_cpu_slices_partition_the_cpus():
+    from magnet_amd import dist as mdist
+    cpus = list(range(3, 3 + 20))
+    parts = [mdist.cpu_slice(r, 8, cpus) for r in range(8)]
+    assert sorted(c for p in parts for c in p) == cpus and max(map(len, parts)) - min(map(len, parts)) <= 1
+    assert all(p == list(range(p[0], p[0] + len(p))) for p in parts)      # contiguous
+    assert mdist.cpu_slice(2, 8, [0, 1, 2]) == [0, 1, 2]                  # fewer CPUs than ranks: no pinning
+    assert mdist.cpu_slice(0, 1, cpus) == cpus
