@@ -28,7 +28,7 @@
 //   * no fp64, no exec-mask branches around the gate / combine
 // Everything that needs the reference's exact rounding (explicit d_volume, est_costvolume_F mode, stats) stays in
 // cost_volume_cand.hip / cost_volume.hip.
-#include "cv_fast_common.hpp"
+#include "cv_runs.hpp"
 
 namespace magnet {
 
@@ -122,8 +122,10 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
     const size_t map_texels = (size_t)Hp * Wp;
     // source view v of frame b is image v*B + b (view-major, homography.py:105): walk the views by a constant stride
     const size_t src_vstride = (size_t)p.B * map_texels * texel_bytes, sgm_vstride = (size_t)p.B * map_texels * 8;
-    const unsigned char* const src_b = reinterpret_cast<const unsigned char*>(p.src_feat) + (size_t)b * map_texels * texel_bytes;
-    const unsigned char* const sgm_b = reinterpret_cast<const unsigned char*>(p.src_gmm) + (size_t)b * map_texels * 8;
+    // (round 4) frame bases pinned into SGPRs as GLOBAL pointers: base + 32-bit lane offset selects the scalar-base addressing mode; the
+    // 64-bit multiply above runs on the vector unit, so these bases used to be per-lane register pairs (one v_lshl_add_u64 per load)
+    const cvr_gptr src_b = (cvr_gptr)(unsigned long long)v4_uniform_ptr(reinterpret_cast<const unsigned char*>(p.src_feat) + (size_t)b * map_texels * texel_bytes);
+    const cvr_gptr sgm_b = (cvr_gptr)(unsigned long long)v4_uniform_ptr(reinterpret_cast<const unsigned char*>(p.src_gmm) + (size_t)b * map_texels * 8);
     const float kappa = p.kappa;
 
     for (int jb = 0; jb < JB; ++jb) {                                             // candidate block of DL candidates
@@ -163,10 +165,11 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
             d = live ? d : __builtin_nanf("");                                    // dead lane -> out of image below
             float acc = 0.f;
 
-            const unsigned char* __restrict__ src = src_b;
-            const unsigned char* __restrict__ sgm = sgm_b;
-            for (int v = 0; v < p.V; ++v, src += src_vstride, sgm += sgm_vstride) {
+            for (int v = 0; v < p.V; ++v) {
                 if (!((vmask >> v) & 1ull)) continue;                            // homography.py:97 (wave-uniform)
+                // the view's bases, pinned again: the 64-bit view stride is a vector-unit product
+                const cvr_gptr src = (cvr_gptr)(unsigned long long)v4_uniform_ptr((const void*)(src_b + (size_t)v * src_vstride));
+                const cvr_gptr sgm = (cvr_gptr)(unsigned long long)v4_uniform_ptr((const void*)(sgm_b + (size_t)v * sgm_vstride));
                 // ---------------- geometry ----------------
                 const float4 pa = pvtab[(v * 16 + q) * 2 + 0], pb = pvtab[(v * 16 + q) * 2 + 1];
                 const float Px = __builtin_fmaf(pa.x, d, pb.x);                  // homography.py:132
@@ -191,14 +194,14 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                     const unsigned long long lbal = __builtin_amdgcn_ballot_w64(lead);
                     const int run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lbal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lbal, lead ? 1u : 0u));
                     if (lead) {
-                        gslot[run * 2 + 0] = *reinterpret_cast<const float4*>(sgm + qi * 8u);
-                        gslot[run * 2 + 1] = *reinterpret_cast<const float4*>(sgm + (qi + (uint32_t)Wp) * 8u);
+                        gslot[run * 2 + 0] = v3_gld_f4(sgm + qi * 8u);
+                        gslot[run * 2 + 1] = v3_gld_f4(sgm + (qi + (uint32_t)Wp) * 8u);
                     }
                     fwave_lds_fence();
                     g0 = gslot[run * 2 + 0]; g1 = gslot[run * 2 + 1];
                 } else if (!NOGMM) {
-                    g0 = *reinterpret_cast<const float4*>(sgm + qi * 8u);                 // (mu,sg) x0, x0+1 of row y0
-                    g1 = *reinterpret_cast<const float4*>(sgm + (qi + (uint32_t)Wp) * 8u);
+                    g0 = v3_gld_f4(sgm + qi * 8u);                 // (mu,sg) x0, x0+1 of row y0
+                    g1 = v3_gld_f4(sgm + (qi + (uint32_t)Wp) * 8u);
                 }
                 float mu_w = g0.x * wnw, sg_w = g0.y * wnw;
                 mu_w = __builtin_fmaf(g0.z, wne, mu_w); sg_w = __builtin_fmaf(g0.w, wne, sg_w);
@@ -230,10 +233,10 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                     // ends up with C[reg t] = <ref, src[item g4, tap t]>
                     for (int ps = 0; ps < nitems; ps += 4) {
                         const uint32_t item = items[min(ps + upair, nitems)];
-                        const unsigned char* sp = src + (__umul24(item, texel_bytes) + lane_src_off);
+                        const cvr_gptr sp = src + (__umul24(item, texel_bytes) + lane_src_off);
                         uint4 av[KS];
 #pragma unroll
-                        for (int ks = 0; ks < KS; ++ks) av[ks] = *reinterpret_cast<const uint4*>(sp + ks * 64);
+                        for (int ks = 0; ks < KS; ++ks) av[ks] = v3_gld_u4(sp + ks * 64);
                         ff32x4_t c4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks)
@@ -253,12 +256,12 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                             if (a == 1 && !second) break;
                             const int it = min(IPP * (ps + a) + upair, nitems);   // tail of the last pass: the pad item
                             const uint32_t item = items[it];
-                            const unsigned char* sp = src + (__umul24(item & 0xffffffu, texel_bytes) + lane_src_off);
+                            const cvr_gptr sp = src + (__umul24(item & 0xffffffu, texel_bytes) + lane_src_off);
                             const unsigned char* rp = refl + (__umul24((item >> 26) & 7u, texel_bytes) + (uint32_t)sub * 16u);   // LDS (PPW > 1 only)
 #pragma unroll
                             for (int cc = 0; cc < CPL; ++cc) {
                                 const bool okc = FULL || (sub + LPU * cc < nchunk);
-                                sv[a][cc] = okc ? *reinterpret_cast<const uint4*>(sp + cc * CSTR) : make_uint4(0, 0, 0, 0);
+                                sv[a][cc] = okc ? v3_gld_u4(sp + cc * CSTR) : make_uint4(0, 0, 0, 0);
                                 if (PPW == 1) rv[a][cc] = rvp[cc];
                                 else rv[a][cc] = okc ? *reinterpret_cast<const uint4*>(rp + cc * CSTR) : make_uint4(0, 0, 0, 0);
                             }

@@ -14,7 +14,7 @@
 //
 // Arithmetic, tolerance contract, layouts: exactly cost_volume_fast.hip (see its header).
 #include <stdlib.h>
-#include "cv_fast_common.hpp"
+#include "cv_runs.hpp"
 
 namespace magnet {
 
@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
     // 32 bits (checked by the launcher)
     const uint32_t src_vstride = (uint32_t)((size_t)p.B * map_texels * texel_bytes);
     const size_t sgm_vstride = (size_t)p.B * map_texels * 8;
-    const unsigned char* const src_b = reinterpret_cast<const unsigned char*>(p.src_feat) + (size_t)b * map_texels * texel_bytes;
-    const unsigned char* const sgm_b = reinterpret_cast<const unsigned char*>(p.src_gmm) + (size_t)b * map_texels * 8;
+    // (round 4) frame bases pinned into SGPRs as GLOBAL pointers (scalar-base addressing mode of the vector loads; see cost_volume_v3.hip)
+    const cvr_gptr src_b = (cvr_gptr)(unsigned long long)v4_uniform_ptr(reinterpret_cast<const unsigned char*>(p.src_feat) + (size_t)b * map_texels * texel_bytes);
+    const cvr_gptr sgm_b = (cvr_gptr)(unsigned long long)v4_uniform_ptr(reinterpret_cast<const unsigned char*>(p.src_gmm) + (size_t)b * map_texels * 8);
     const float kappa = p.kappa;
 
     for (int jb = 0; jb < JB; ++jb) {                                             // candidate block of 64 candidates
@@ -132,10 +133,10 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
 #pragma unroll
                     for (int a = 0; a < NPASS; ++a) {
                         if (a > 0 && ps + IPP * a >= n) break;                    // wave-uniform: this pass holds no item
-                        const unsigned char* sp = src_b + (off[a] + lane_src_off);
+                        const cvr_gptr sp = src_b + (off[a] + lane_src_off);
 #pragma unroll
                         for (int cc = 0; cc < CPL; ++cc)
-                            sv[a][cc] = (FULL || (sub + LPU * cc < nchunk)) ? *reinterpret_cast<const uint4*>(sp + cc * CSTR) : make_uint4(0, 0, 0, 0);
+                            sv[a][cc] = (FULL || (sub + LPU * cc < nchunk)) ? v3_gld_u4(sp + cc * CSTR) : make_uint4(0, 0, 0, 0);
                     }
 #pragma unroll
                     for (int a = 0; a < NPASS; ++a) {
@@ -189,10 +190,10 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
                         const uint32_t xq = (uint32_t)__builtin_amdgcn_fmed3f(x0f, 0.0f, (float)p.w);
                         const uint32_t yq = (uint32_t)__builtin_amdgcn_fmed3f(y0f, 0.0f, (float)p.h);
                         qi[u] = __umul24(yq, (uint32_t)Wp) + xq;                 // quad origin in the padded map (exact when inwin)
-                        const unsigned char* __restrict__ sgm = sgm_b + (size_t)vv * sgm_vstride;
+                        const cvr_gptr sgm = (cvr_gptr)(unsigned long long)v4_uniform_ptr((const void*)(sgm_b + (size_t)vv * sgm_vstride));
                         if (!LEAD) {
-                            g0[u] = *reinterpret_cast<const float4*>(sgm + qi[u] * 8u);             // (mu,sg) x0, x0+1 of row y0
-                            g1[u] = *reinterpret_cast<const float4*>(sgm + (qi[u] + (uint32_t)Wp) * 8u);
+                            g0[u] = v3_gld_f4(sgm + qi[u] * 8u);             // (mu,sg) x0, x0+1 of row y0
+                            g1[u] = v3_gld_f4(sgm + (qi[u] + (uint32_t)Wp) * 8u);
                         }
                     }
                     if (LEAD) {
@@ -202,15 +203,15 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
 #pragma unroll
                         for (int u = 0; u < VG; ++u) {
                             const int vv = min(v0 + u, p.V - 1);
-                            const unsigned char* __restrict__ sgm = sgm_b + (size_t)vv * sgm_vstride;
+                            const cvr_gptr sgm = (cvr_gptr)(unsigned long long)v4_uniform_ptr((const void*)(sgm_b + (size_t)vv * sgm_vstride));
                             const uint32_t tkey = inwin[u] ? qi[u] : FKEY_CLOSED;
                             const uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);
                             const bool lead = inwin[u] && (tkey != tprev);
                             const unsigned long long lbal = __builtin_amdgcn_ballot_w64(lead);
                             run[u] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lbal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lbal, lead ? 1u : 0u));
                             if (lead) {
-                                gslot[(u * 65 + run[u]) * 2 + 0] = *reinterpret_cast<const float4*>(sgm + qi[u] * 8u);
-                                gslot[(u * 65 + run[u]) * 2 + 1] = *reinterpret_cast<const float4*>(sgm + (qi[u] + (uint32_t)Wp) * 8u);
+                                gslot[(u * 65 + run[u]) * 2 + 0] = v3_gld_f4(sgm + qi[u] * 8u);
+                                gslot[(u * 65 + run[u]) * 2 + 1] = v3_gld_f4(sgm + (qi[u] + (uint32_t)Wp) * 8u);
                             }
                         }
                         fwave_lds_fence();
