@@ -342,8 +342,11 @@ __device__ __forceinline__ f32x4_t cv_mma(const bf16x8_t& a, const bf16x8_t& b, 
 // __launch_bounds__(NT, 2): two waves per SIMD is what the LDS budget allows anyway, and with <= 256 registers hipcc selects the
 // VGPR form of the MFMAs — with the default bound it kept the accumulators in AGPRs and moved all 64 of them through VGPRs
 // (64 v_accvgpr_read + 64 v_accvgpr_write) on every trip of the K loop.
-template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, int WIN = 0>
-__global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
+// One output tile (CV_BM rows x BN channels).  `bid` of `n_tiles`: the tile's position in launch order (the block id of a one-tile-per-
+// workgroup launch, the loop counter of a persistent one); `by`: the channel block.
+template <int NF, int WN, int CV_BM, int SPB, int TAIL, int NT, bool PP, int WIN>
+__device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, unsigned char* const smem, const unsigned bid, const unsigned n_tiles, const unsigned by,
+                                               const int tid) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins do not exist in the host pass (which only needs the stub)
     constexpr int BN = NF * 16;
     constexpr int RP = NT / 4;                        // tile rows filled by one DMA instruction per wave set (4 lanes per 64-byte row)
@@ -355,19 +358,17 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
     constexpr int AW_ROWS = WIN ? CV_BM + 8 : CV_BM;           // window: up to (3-1)*2 extra rows (dilation 2), padded to 8
     constexpr int A_BYTES = AW_ROWS * CV_ROW, B_BYTES = BN * CV_ROW;
     constexpr int STAGE_BYTES = 2 * A_BYTES + 2 * B_BYTES;    // hi + lo planes of A and B
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // ring of 2*SPB stages
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     // XCD-aware tile order: hardware deals consecutive block ids round-robin to the 8 XCDs; remap so each XCD (one
     // private L2) owns a contiguous run of row tiles — vertically adjacent tiles share their halo rows (bijective).
     long long tile_id;
     {
-        const unsigned n = gridDim.x, bid = blockIdx.x, q = n / 8, r = n % 8, xcd = bid % 8, idx = bid / 8;
+        const unsigned n = n_tiles, q = n / 8, r = n % 8, xcd = bid % 8, idx = bid / 8;
         tile_id = (long long)((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const long long row0 = tile_id * CV_BM;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = by * BN;
 
     // staging by LDS-DMA (global_load_lds_dwordx4: global -> LDS without a VGPR round trip or ds_write): a
     // 64-byte K-slice of one row = 4 x 16 B; thread -> (row = tid>>2 (+64, +128 ...), physical slot = tid&3).  The DMA
@@ -1589,6 +1590,38 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
 #endif
 }
 
+// PERSIST (round 4, dev only): one workgroup per CU walks the tiles bid, bid + gridDim.x, ... instead of one workgroup per tile.
+// tools/conv_kscale.py splits the 8-wave kernel's launch time into 182 us per 32-channel group (507 TFLOP/s fp32-equivalent inside the K
+// loop) + 0.16 - 0.20 ms that do not depend on K (10 - 12 % at K = 9 x 256: ~10 us per tile).  The bet was that those are workgroup
+// relaunch, kernel-argument loads and the drain of the epilogue's stores, which a persistent loop removes (no vmcnt wait between tiles:
+// the K loops' counted waits only get stricter with stores outstanding).  Measured (profiles/r4/conv_persistent_ab.log): 1.616 vs
+// 1.604 ms at K = 9 x 256, 2.134 vs 2.118 / 1.950 vs 1.914 ms on the two fused-tail stacks — the hardware's own relaunch already costs
+// nothing; the fixed part is the tile's exposed first-stage DMA latency, the ping-pong ramp and the epilogue, which only a next-tile
+// prefetch issued BEFORE the epilogue could hide (LDS for it exists only in the TAIL = 0 kernel).  Kept for that experiment.
+template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, int WIN = 0, bool PERSIST = false>
+__global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // ring of 2*SPB stages
+    if constexpr (PERSIST) {
+        const unsigned n_tiles = (unsigned)((p.rows + CV_BM - 1) / CV_BM);     // (loop-invariant hoisting is the trap of this form: see below)
+        for (unsigned t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+            // the tail's weight / bias loads have the same addresses for every tile: opaque pointers per trip, or the compiler hoists
+            // hundreds of registers of them out of this loop (first version: 1.2 - 2 KB of scratch per lane)
+            ConvParams q = p;
+            asm volatile("" : "+s"(q.tail_w_hi), "+s"(q.tail_w_lo), "+s"(q.tail_bias), "+s"(q.bias), "+s"(q.w_hi), "+s"(q.w_lo));
+            // ... and an opaque thread id: every per-lane constant of a tile (fragment offsets, DMA offsets, the tails' column indices) is
+            // the same for each tile, and hoisted out of the loop they would all be live across it
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            conv_mfma_tile<NF, WN, CV_BM, SPB, TAIL, NT, PP, WIN>(q, smem, t, n_tiles, blockIdx.y, tid);
+            // the epilogue's LDS reads (staging rows, the tail's activation tile) retire before any wave's next-tile DMA lands
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        conv_mfma_tile<NF, WN, CV_BM, SPB, TAIL, NT, PP, WIN>(p, smem, blockIdx.x, gridDim.x, blockIdx.y, threadIdx.x);
+    }
+}
+
 template <int NF, int WN, int BM, int SPB, int NT = 256, bool PP = false, int WIN = 0>
 static size_t conv_lds_bytes() {
     const size_t tiles = (WIN == 4 && PP) ? 2 * (2 * (size_t)(BM + 8) * CV_ROW + 512 * 4) + 4 * (size_t)(NF * 16) * CV_ROW + 2 * (3 * (size_t)(NF * 16) * CV_ROW + 512 * 4 + 16)
@@ -1601,19 +1634,35 @@ static size_t conv_lds_bytes() {
     return tiles > stage ? tiles : stage;
 }
 
-template <int NF, int WN, int BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, int WIN = 0>
+static int conv_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+template <int NF, int WN, int BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, int WIN = 0, bool PERSIST = false>
 static hipError_t launch_conv_nf(const ConvParams& p, hipStream_t s) {
-    const dim3 grid((unsigned)((p.rows + BM - 1) / BM), (unsigned)(p.cout_pad / (NF * 16))), block(NT);
+    dim3 grid((unsigned)((p.rows + BM - 1) / BM), (unsigned)(p.cout_pad / (NF * 16))), block(NT);
     size_t lds = conv_lds_bytes<NF, WN, BM, SPB, NT, PP, WIN>();
     if (TAIL > 0 && lds < (size_t)BM * 512) lds = (size_t)BM * 512;     // the fused tail's activation tile: BM rows x 256 B x (hi, lo)
     if (TAIL == 9 && lds < (size_t)128 * 148 * 4) lds = (size_t)128 * 148 * 4;   // fused upsampling: 128 rows x 144 logits (+4 pad) fp32 (two 4-wave workgroups still fit a CU)
+    if (PERSIST) {
+        // one workgroup per CU (these tiles take more than half a CU's LDS); a multiple of 8 keeps a workgroup's tiles on one XCD
+        unsigned ncu = (unsigned)conv_cu_count() / 8 * 8;
+        if (ncu == 0) ncu = 8;
+        if (grid.x > ncu) grid.x = ncu;
+    }
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {          // > 64 KiB of dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP, WIN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP, WIN, PERSIST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP, WIN>), grid, block, lds, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP, WIN, PERSIST>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
@@ -1667,6 +1716,13 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
         }
         if (win && p.tap_n == 3 && !(p.variant & (16 | 8)) && p.rows >= 256ll * 256 && (!p.addend || (p.variant & 256))) {   // dev (MAGNET_CONV_VARIANT=256): 8-wave form for addend launches too
                                                                 // dev (MAGNET_CONV_VARIANT=16): the 4-wave register-window loop below
+#ifdef MAGNET_DEV
+            if (p.variant & 4096) {                             // dev (MAGNET_CONV_VARIANT=4096): persistent workgroups (see conv_mfma_kernel): 0.7 % SLOWER
+                if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 2, true>(p, s);
+                if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 2, true>(p, s);
+                if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true, 2, true>(p, s);
+            }
+#endif
             if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 2>(p, s);
             if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 2>(p, s);
             if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true, 2>(p, s);
@@ -1692,7 +1748,12 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
     // register-window loop (same-box: C3 step -1 %); on the F-Net's plain 128-wide layers (split-bf16 outputs) it is equal to the
     // 4-wave loop (18.64 - 18.72 vs 18.69 - 18.75 ms per 40 images; dev MAGNET_CONV_VARIANT=2048 forces it there)
     if (p.cout_pad == 128 && p.tap_n == 3 && (p.out_mode == 1 || (p.variant & 2048)) && !(p.variant & (16 | 9)) && p.rows >= 256ll * 256 && !p.add_hi && !p.img_rows)
+    {
+#ifdef MAGNET_DEV
+        if (p.variant & 4096) return launch_conv_nf<8, 2, 256, 1, 0, 512, true, 2, true>(p, s);
+#endif
         return launch_conv_nf<8, 2, 256, 1, 0, 512, true, 2>(p, s);
+    }
     if (p.cout_pad % 128 == 0 && p.tap_n == 3 && !(p.variant & 9) && !pp) return launch_conv_nf<8, 2, 128, 1, 0, 256, false, 2>(p, s);
     if (p.cout_pad % 128 == 0 && p.tap_n > 1 && !(p.variant & 1) && !pp) return launch_conv_nf<8, 2, 128, 1, 0, 256, false, 1>(p, s);
     if (p.cout_pad % 128 == 0 && pp) return launch_conv_nf<8, 2, 256, 1, 0, 512, true>(p, s);
