@@ -1504,12 +1504,34 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, unsigned cha
         return;
     }
 
+#ifdef MAGNET_DEV
+    if (p.variant & 8192) return;                              // dev timing ablation (tools/conv_kscale.py): no epilogue
+#endif
     // ---- epilogue through LDS, one 16-row fragment per wave at a time: [16 rows][NFW*16] fp32 per wave ----
+    // Round 4 (tools/conv_kscale.py, profiles/r4/conv_no_epilogue.log): of the 8-wave kernel's 0.16 ms that do not depend on K (10 % of
+    // the launch at K = 9 x 256), 0.13 ms is this epilogue = 6.6 us per tile = the tile's 128 KB at ~20 GB/s per CU — x 256 CUs in
+    // lockstep (one workgroup per CU, equal tile times) 5 - 6 TB/s: the stores of all tiles arrive as ONE burst at the fabric's write
+    // rate while the matrix pipes idle.  Tried against it: (1) persistent workgroups (see conv_mfma_kernel; no gain: a wave's loads and
+    // stores share vmcnt, so the next tile's first counted wait still drains the stores); (2) start skew of the first-round workgroups
+    // by eighths of a tile time (conv_start_skew.log: fixed part 0.162 -> 0.118 ms, but the late starters end the launch late: +3 % at
+    // K = 9 x 512, -2.6 % at K = 9 x 64, a wash at the G-Net shapes); (3) C^T accumulators stored straight from registers, no LDS stage
+    // (conv_direct_epilogue.log: fp32 outputs -1.5 % at K = 9 x 128, but the bf16 planes leave as 8-byte stores = 32-byte row segments and
+    // the F-Net slows down 18.4 -> 19.3 ms).  What would remove it is an epilogue that overlaps another tile's K loop on the same CU
+    // (two co-resident workgroups out of phase: needs the 8-wave loop in <= 80 KB of LDS and <= 128 registers) — not built.
     const long long tile_img = p.img_rows ? row0 / p.img_rows : 0;            // wave-uniform (scalar) division, once
     const int tile_rem = p.img_rows ? (int)(row0 - tile_img * p.img_rows) : 0;
     const float inv_wp = 1.0f / (float)(p.wp > 0 ? p.wp : 1);
     constexpr int WCOLS = NFW * 16, SROW = WCOLS + 4;          // +4 floats row pad
     float* stage = reinterpret_cast<float*>(smem) + wv * (16 * SROW);
+    // a lane's work items of every fragment cover the same 8 channels when 64 is a multiple of the items per row: its bias values are
+    // loaded once per tile (they used to be re-loaded behind every staging read)
+    constexpr bool BIAS_INV = (64 % (WCOLS / 8)) == 0;
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (BIAS_INV) {
+        const int ch = n0 + wn * WCOLS + (lane % (WCOLS / 8)) * 8;
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ch), b1 = *reinterpret_cast<const float4*>(p.bias + ch + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
 #pragma unroll
     // the staging rows are wave-private: after the K loop's final barrier (every wave is done with the ring) only the
     // wave's own LDS accesses need ordering — in-order in hardware, a scheduling fence for the compiler — no workgroup barrier
@@ -1565,7 +1587,7 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, unsigned cha
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float x = (stage[r * SROW + c8 + i] + ad[i]) + p.bias[ch + i];
+                float x = (stage[r * SROW + c8 + i] + ad[i]) + (BIAS_INV ? bv[i] : p.bias[ch + i]);
                 v[i] = (p.relu && x < 0.f) ? 0.f : x;
                 if (!interior) v[i] = 0.f;
             }
