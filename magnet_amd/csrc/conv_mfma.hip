@@ -345,9 +345,10 @@ __device__ __forceinline__ f32x4_t cv_mma(const bf16x8_t& a, const bf16x8_t& b, 
 // One output tile (CV_BM rows x BN channels).  `bid` of `n_tiles`: the tile's position in launch order (the block id of a one-tile-per-
 // workgroup launch, the loop counter of a persistent one); `by`: the channel block.
 template <int NF, int WN, int CV_BM, int SPB, int TAIL, int NT, bool PP, int WIN>
-__device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, unsigned char* const smem, const unsigned bid, const unsigned n_tiles, const unsigned by,
-                                               const int tid) {
+__device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsigned bid, const unsigned n_tiles, const unsigned by, const int tid) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins do not exist in the host pass (which only needs the stub)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // ring of 2*SPB stages (declared here, not passed in: a pointer
+                                                                            // parameter is a generic pointer, and its casts to LDS pointers get null checks)
     constexpr int BN = NF * 16;
     constexpr int RP = NT / 4;                        // tile rows filled by one DMA instruction per wave set (4 lanes per 64-byte row)
     constexpr int A_PT = CV_BM / RP;                           // 16-byte vectors per thread per A plane (2 or 4)
@@ -1109,17 +1110,26 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, unsigned cha
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) a_offx[tx] = cv_swz(wm * (MF * 16) + frow + tx * p.tap_sx, lane >> 4);
         bf16x8_t ah[3][MF], al[3][MF], fbh[NFW], fbl[NFW];
+#ifdef CONV_ABL      // ablation builds: LDS reads by 32-bit address (a conditional read through the generic pointer trips a backend bug: null check of the LDS cast)
+        typedef uint32_t cv_u32x4 __attribute__((ext_vector_type(4)));
+#define CV_LD16(ptr) (*reinterpret_cast<const __attribute__((address_space(3))) cv_u32x4*>((uint32_t)(uintptr_t)(ptr)))
+#else
+#define CV_LD16(ptr) (*reinterpret_cast<const uint4*>(ptr))
+#endif
         auto load_b = [&](int slot) {
             const unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
             const unsigned char* sb_lo = sb_hi + B_BYTES;
 #pragma unroll
             for (int n = 0; n < NFW; ++n) {
-                fbh[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
-                fbl[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_lo + b_off + n * 16 * CV_ROW));
+                fbh[n] = __builtin_bit_cast(bf16x8_t, CV_LD16(sb_hi + b_off + n * 16 * CV_ROW));
+                fbl[n] = __builtin_bit_cast(bf16x8_t, CV_LD16(sb_lo + b_off + n * 16 * CV_ROW));
             }
         };
         auto mfmas = [&](const bf16x8_t (&xh)[MF], const bf16x8_t (&xl)[MF]) {
             __builtin_amdgcn_s_setprio(1);
+#if defined(CONV_ABL) && (CONV_ABL & 8)
+            if (false)
+#endif
 #pragma unroll
             for (int n = 0; n < NFW; ++n) {
 #pragma unroll
@@ -1137,43 +1147,62 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, unsigned cha
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");                    \
         __builtin_amdgcn_s_barrier();
         const int grp = __builtin_amdgcn_readfirstlane(wv >> 2);
+#ifdef CONV_ABL
+        // timing ablations, compile-time (hipcc -DMAGNET_DEV -DCONV_ABL=bits; results are wrong): 1 no DMA inside the loop, 2 no weight-fragment
+        // reads, 4 no window reads, 8 no MFMAs
+        constexpr bool abl_dma = (CONV_ABL & 1) != 0, abl_b = (CONV_ABL & 2) != 0, abl_a = (CONV_ABL & 4) != 0;
+#else
+        constexpr bool abl_dma = false, abl_b = false, abl_a = false;
+#endif
         dma_a();
         dma_b(0);
         dma_b(1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BP) : "memory");                 // window 0 and stage 0 landed (this wave's pieces)
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier (= half a sub-step) behind group 0
-        for (int g = 0; g < ngroups; ++g) {
-            const bool lastg = g + 1 == ngroups;
-            // ---- tx = 0 ----
-            asm volatile("" ::: "memory");
+        if constexpr (abl_a) {
 #pragma unroll
             for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
                 for (int m = 0; m < MF; ++m) {
-                    ah[tx][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + a_offx[tx] + m * 16 * CV_ROW));
-                    al[tx][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + A_BYTES + a_offx[tx] + m * 16 * CV_ROW));
+                    ah[tx][m] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + a_offx[tx] + m * 16 * CV_ROW));
+                    al[tx][m] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + A_BYTES + a_offx[tx] + m * 16 * CV_ROW));
                 }
-            load_b(0);
-            dma_b(2);                                         // stage 3g + 2
+        }
+        if constexpr (abl_b) load_b(0);
+        for (int g = 0; g < ngroups; ++g) {
+            const bool lastg = g + 1 == ngroups;
+            // ---- tx = 0 ----
+            asm volatile("" ::: "memory");
+            if constexpr (!abl_a)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int m = 0; m < MF; ++m) {
+                    ah[tx][m] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + a_offx[tx] + m * 16 * CV_ROW));
+                    al[tx][m] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + A_BYTES + a_offx[tx] + m * 16 * CV_ROW));
+                }
+            if constexpr (!abl_b) load_b(0);
+            if constexpr (!abl_dma) dma_b(2);                           // stage 3g + 2
             CV_END_LOAD(BP)                                   // stage 3g + 1 landed
             mfmas(ah[0], al[0]);
             // ---- tx = 1 ----
             asm volatile("" ::: "memory");
-            load_b(1);
+            if constexpr (!abl_b) load_b(1);
             if (!lastg) {
-                dma_b(0); dma_a();                            // stage 3g + 3, window g + 1
+                if constexpr (!abl_dma) { dma_b(0); dma_a(); }          // stage 3g + 3, window g + 1
                 if (wv == 0) { CV_END_LOAD(BP + AP + 2) } else { CV_END_LOAD(BP + AP) }      // stage 3g + 2 landed
             } else { CV_END_LOAD(0) }
             mfmas(ah[1], al[1]);
             // ---- tx = 2 ----
             asm volatile("" ::: "memory");
-            load_b(2);
-            if (!lastg) { dma_b(1); CV_END_LOAD(BP) }         // stage 3g + 4; stage 3g + 3 and window g + 1 landed
+            if constexpr (!abl_b) load_b(2);
+            if (!lastg) { if constexpr (!abl_dma) dma_b(1); CV_END_LOAD(BP) }         // stage 3g + 4; stage 3g + 3 and window g + 1 landed
             else { CV_END_LOAD(0) }
             mfmas(ah[2], al[2]);
         }
 #undef CV_END_LOAD
+#undef CV_LD16
         if (grp == 0) __builtin_amdgcn_s_barrier();           // balance group 1's extra barrier
         __syncthreads();                                      // nothing in flight; the ring is dead
     } else
@@ -1622,7 +1651,6 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, unsigned cha
 // prefetch issued BEFORE the epilogue could hide (LDS for it exists only in the TAIL = 0 kernel).  Kept for that experiment.
 template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, int WIN = 0, bool PERSIST = false>
 __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // ring of 2*SPB stages
     if constexpr (PERSIST) {
         const unsigned n_tiles = (unsigned)((p.rows + CV_BM - 1) / CV_BM);     // (loop-invariant hoisting is the trap of this form: see below)
         for (unsigned t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -1634,13 +1662,13 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
             // the same for each tile, and hoisted out of the loop they would all be live across it
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
-            conv_mfma_tile<NF, WN, CV_BM, SPB, TAIL, NT, PP, WIN>(q, smem, t, n_tiles, blockIdx.y, tid);
+            conv_mfma_tile<NF, WN, CV_BM, SPB, TAIL, NT, PP, WIN>(q, t, n_tiles, blockIdx.y, tid);
             // the epilogue's LDS reads (staging rows, the tail's activation tile) retire before any wave's next-tile DMA lands
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
     } else {
-        conv_mfma_tile<NF, WN, CV_BM, SPB, TAIL, NT, PP, WIN>(p, smem, blockIdx.x, gridDim.x, blockIdx.y, threadIdx.x);
+        conv_mfma_tile<NF, WN, CV_BM, SPB, TAIL, NT, PP, WIN>(p, blockIdx.x, gridDim.x, blockIdx.y, threadIdx.x);
     }
 }
 

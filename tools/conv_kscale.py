@@ -5,7 +5,9 @@ import sys, torch
 sys.path.insert(0, ".")
 import os
 from magnet_amd import lib
-if os.environ.get("CONV_DEV_LIB"):
+if os.environ.get("CONV_LIB"):
+    lib.LIB_PATH = os.path.abspath(os.environ["CONV_LIB"])      # an ablation build of tools/build_conv_abl.sh
+elif os.environ.get("CONV_DEV_LIB"):
     lib.use_dev_build()      # MAGNET_CONV_VARIANT=4096: the persistent-workgroup form (dev)
 
 def main():
