@@ -13,7 +13,7 @@
 #   ablate_*.log          matcher variants on the dev library (tools/ablate.py), issue_rate / gather_rate microbenchmarks
 # Every profiler pass has a short timeout: some TA/TCP/TD counter sets hang rocprofv3 on this pool.  The --pmc passes run the
 # contract's own 5 + 20 steps, so that the clock / busy counters describe the chip state the bench line was measured in.
-tag=${1:-r3}
+tag=${1:-r4}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$tag; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
@@ -58,7 +58,8 @@ timeout 200 python tools/bench_pipeline.py 2>/dev/null | tail -1 > $O/bench_pipe
 # matcher variants (dev library) + instruction / gather microbenchmarks
 timeout 150 python tools/ablate.py C2 64 split > $O/ablate_C2_split.log 2>&1
 timeout 150 python tools/ablate.py C2 64 > $O/ablate_C2_nchw.log 2>&1
-for u in issue_rate gather_rate mx_split; do
+timeout 100 python tools/conv_kscale.py 2>/dev/null > $O/conv_kscale.log
+for u in issue_rate gather_rate mx_split dma_rate pp_barrier; do
   [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2>/dev/null
   timeout 120 tools/ubench/$u > $O/$u.txt 2>&1
 done
