@@ -116,3 +116,13 @@ def test_host_raises_without_gpu_tensors(hip_lib):
         lib.pack_features(x)
     with pytest.raises(lib.MagnetError, match="no CPU fallback"):
         lib.gaussian_update(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4))
+
+
+def test_graft_entry_version_check_follows_the_header():
+    """__graft_entry__.build() compares the built library with include/magnet_hip.h, not with a literal that goes stale on an ABI bump
+    (round 4: the literal said 301 while the header said 302 — the driver's build check would have failed)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "__graft_entry__.py")).read()
+    assert "MAGNET_HIP_VERSION" in src and not re.search(r"magnet_version\(\)\s*==\s*\d", src)
