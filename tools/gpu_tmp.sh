@@ -1,23 +1,13 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/persist; mkdir -p $O
-: > $O/abl_clock.log
-for a in dev 1 7 8; do
-  if [ $a = dev ]; then L=magnet_amd/libmagnet_hip_dev.so; else L=magnet_amd/libmagnet_hip_abl$a.so; fi
-  rm -rf $O/pc
-  CONV_LIB=$L MAGNET_CONV_VARIANT=8192 timeout 120 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pc -o p -- python tools/conv_kscale.py > /dev/null 2>&1
-  python - $a $O/pc >> $O/abl_clock.log <<'PY'
-import csv,glob,sys,collections
-a,d=sys.argv[1],sys.argv[2]
-agg=collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(d+"/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "conv_mfma_kernel" not in r["Kernel_Name"]: continue
-        dur=float(r["End_Timestamp"])-float(r["Start_Timestamp"])
-        key=round(dur/1e5)  # bucket by ~0.1 ms: the four input widths
-        agg[key][r["Counter_Name"]].append(float(r["Counter_Value"])); agg[key]["dur"].append(dur)
-for k in sorted(agg):
-    v=agg[k]; dur=sum(v["dur"])/len(v["dur"]); g=sum(v["GRBM_GUI_ACTIVE"])/len(v["GRBM_GUI_ACTIVE"])/8; m=sum(v["SQ_VALU_MFMA_BUSY_CYCLES"])/len(v["SQ_VALU_MFMA_BUSY_CYCLES"])/1024
-    print(f"lib {a:>3}: launch {dur/1e6:.3f} ms  clock {g/dur:.3f} GHz  matrix pipe busy {100*m/g:.1f} %")
-PY
-done
-cat $O/abl_clock.log
+cd $GRAFT_REPO_ROOT; O=gpurun_out/hotbox; mkdir -p $O
+b() { python bench.py --no-pmc --no-cpu-baseline --sustain-s 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value'],1), 'frames/s', round(d['ms_per_step'],3), 'ms  matcher', round(d['roofline']['avg_launch_ms'],4), ' conv TF', round(d['roofline_conv']['achieved'],1))"; }
+{
+rocm-smi --showtemp --showpower --showclocks 2>/dev/null | grep -i "temp\|power\|sclk" | head -8
+b fresh1; b fresh2
+timeout 300 python -m pytest tests/test_gpu_fast_matcher.py tests/test_gpu_conv.py -q -m gpu 2>&1 | tail -1
+rocm-smi --showtemp --showpower 2>/dev/null | grep -i "temp\|power" | head -6
+b after_tests1; b after_tests2
+python bench.py --no-pmc --no-cpu-baseline --sustain-s 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('with 20 s sustained', round(d['value'],1), round(d['sustained_frames_per_s'],1))"
+rocm-smi --showtemp --showpower 2>/dev/null | grep -i "temp\|power" | head -6
+b after_sustain
+} 2>&1 | tee $O/hotbox.log
