@@ -130,6 +130,10 @@ __device__ __forceinline__ void tail_layer(const uint16_t* __restrict__ w_hi, co
 // tails ran at half the K loop's efficiency) and reads every row's activations from LDS (256 B/clk, cheap).  A remainder
 // fragment (TAILN % 4 == 1: the 16-channel G-Net head, the 9th fragment of the 144-channel mask head) is row-split over the
 // waves.  The layer's output replaces its input in place: one barrier after the last read, one after the last write.
+// (Round 4 measured a 2 (row halves) x 4 (column groups) ownership for the 8-wave form — half the fragment reads from LDS, twice the
+// weights through the vector-memory path, bit-identical results: 2.07 - 2.09 / 1.90 - 1.93 ms against 2.07 - 2.08 / 1.88 - 1.89 ms for
+// this form on the two stacks, same box (profiles/r4/conv_tail_ownership_ab.log).  Not kept: the tails, like the K loop, do not speed
+// up by moving load between pipes.)
 template <int TAILN, bool LAST, int ROWS, int NW = 4, bool UP = false>
 __device__ __forceinline__ void tail_layer_cols(const uint16_t* __restrict__ w_hi, const uint16_t* __restrict__ w_lo,
                                                 const float* __restrict__ bias, unsigned char* act_hi, unsigned char* act_lo,

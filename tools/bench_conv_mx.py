@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn as nn
 from magnet_amd import lib
 from magnet_amd.convnet import ConvStackMFMA
-if os.environ.get("CONV_DEV_LIB"):
+if os.environ.get("CONV_LIB"):
+    lib.LIB_PATH = os.path.abspath(os.environ["CONV_LIB"])      # a build of tools/build_conv_abl.sh
+elif os.environ.get("CONV_DEV_LIB"):
     lib.use_dev_build()      # MAGNET_CONV_VARIANT then selects K-loop variants / timing ablations (4096: no correction MFMAs, 8192: no correction operand reads)
 dev = torch.device("cuda:0")
 B, h, w = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 120, 160
