@@ -134,26 +134,22 @@ def cpu_baseline(wl, model_cpu, iters, budget_s=10.0):
                                    f"x{cores} threads; 1 call on 1 frame x1 thread"}
 
 
-def live_counters(wl, B, fdt, timeout_s=90):
-    """rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ instruction counters: separate runs, as the guide
-    prescribes) over `bench.py --kernel-only` of the same workload, in child processes.  HBM bytes per launch =
-    FETCH_SIZE [KB] x 1024 x 2.0 (gfx950 tallies 128-byte read requests at 64 B: MI355X_MICROARCH.md, HBM) + WRITE_SIZE [KB] x 1024
-    (x 1.000 on a 1 GiB device copy: profiles/r1, r2).  Returns (traffic_bytes, source_text, sq_dict) or (None, None, None)."""
+def _pmc_passes(passes, child_args, kernel_match, timeout_s=90):
+    """One rocprofv3 --kernel-trace --pmc child run of this script per counter group (the guide: counters in their own runs, never
+    combined with tracing domains other than the kernel trace).  Returns {counter: mean per dispatch} over the dispatches whose kernel
+    name `kernel_match` accepts, plus "_ns" = their mean duration; {} for a group whose pass failed."""
     import csv
     import glob
     import shutil
     import subprocess
     import tempfile
-    if shutil.which("rocprofv3") is None:
-        return None, None, None
-    passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
-              "SQ": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]}
     vals = {}
+    if shutil.which("rocprofv3") is None:
+        return vals
     for tag, ctrs in passes.items():
         tmp = tempfile.mkdtemp(prefix="magnet_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", tmp, "-o", "p", "--",
-               sys.executable, os.path.abspath(__file__), "--kernel-only", "--no-pmc", "--no-cpu-baseline", "--sustain-s", "0",
-               "--steps", "3", "--warmup", "1", "--workload", wl.name, "--frames", str(B), "--feat-dtype", fdt]
+               sys.executable, os.path.abspath(__file__), "--no-pmc", "--no-cpu-baseline", "--sustain-s", "0", *child_args]
         try:
             env = dict(os.environ, TMPDIR="/tmp")
             for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -169,18 +165,35 @@ def live_counters(wl, B, fdt, timeout_s=90):
                 raise
             if rc_ != 0:
                 raise RuntimeError(f"rocprofv3 exited with {rc_}")
-            acc = {}
+            acc, dur = {}, []
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if "cv_" in r["Kernel_Name"] and "_kernel" in r["Kernel_Name"]:
+                    if kernel_match(r["Kernel_Name"]):
                         acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                        dur.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
             for c_, v_ in acc.items():
-                vals[c_] = sum(v_) / len(v_)
+                vals[c_ if c_ not in vals else f"{c_}@{tag}"] = sum(v_) / len(v_)
+            if dur:
+                vals[f"_ns@{tag}"] = sum(dur) / len(dur)
         except Exception as e:                                   # profiler missing / hung / refused: report nothing rather than a stale number
-            print(f"[bench] rocprofv3 pass {tag} failed ({type(e).__name__}); traffic / counters omitted", file=sys.stderr)
+            print(f"[bench] rocprofv3 pass {tag} failed ({type(e).__name__}); its counters are omitted", file=sys.stderr)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    traffic = src = sq = None
+    return vals
+
+
+def live_counters(wl, B, fdt, timeout_s=90):
+    """rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ instruction counters, address-unit busy: separate runs, as
+    the guide prescribes) over `bench.py --kernel-only` of the same workload, in child processes.  HBM bytes per launch =
+    FETCH_SIZE [KB] x 1024 x 2.0 (gfx950 tallies 128-byte read requests at 64 B: MI355X_MICROARCH.md, HBM) + WRITE_SIZE [KB] x 1024
+    (x 1.000 on a 1 GiB device copy: profiles/r1, r2).  Returns (traffic_bytes, source_text, sq_dict, binding_dict) — None for what
+    could not be measured."""
+    passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
+              "SQ": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"],
+              "TA": ["TA_BUSY_avr", "GRBM_GUI_ACTIVE"]}
+    vals = _pmc_passes(passes, ["--kernel-only", "--steps", "3", "--warmup", "1", "--workload", wl.name, "--frames", str(B), "--feat-dtype", fdt],
+                       lambda k: "cv_" in k and "_kernel" in k, timeout_s)
+    traffic = src = sq = binding = None
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         traffic = float(f"{vals['FETCH_SIZE'] * 1024 * 2.0 + vals['WRITE_SIZE'] * 1024:.4g}")
         src = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --kernel-only` of this "
@@ -190,7 +203,44 @@ def live_counters(wl, B, fdt, timeout_s=90):
         sq = {"valu_insts_per_pixel_view": round(vals["SQ_INSTS_VALU"] / iters, 2), "salu_insts_per_pixel_view": round(vals.get("SQ_INSTS_SALU", 0) / iters, 2),
               "vmem_insts_per_pixel_view": round(vals.get("SQ_INSTS_VMEM_RD", 0) / iters, 2), "lds_insts_per_pixel_view": round(vals.get("SQ_INSTS_LDS", 0) / iters, 2),
               "wave_cycles_waiting_frac": round(vals.get("SQ_WAIT_ANY", 0) / max(vals.get("SQ_WAVE_CYCLES", 1), 1), 3)}
-    return traffic, src, sq
+    # which pipe the kernel actually occupies: GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD
+    # (x 4 / 1024 SIMDs); TA_BUSY_avr is the mean over the CUs' texture-address units
+    g_sq, g_ta = vals.get("GRBM_GUI_ACTIVE"), vals.get("GRBM_GUI_ACTIVE@TA", vals.get("GRBM_GUI_ACTIVE"))
+    if g_sq and "SQ_ACTIVE_INST_VALU" in vals:
+        binding = {"valu_busy": round(vals["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * g_sq / 8), 3),
+                   "ta_busy": round(vals["TA_BUSY_avr"] / (g_ta / 8), 3) if "TA_BUSY_avr" in vals and g_ta else None,
+                   "wait_frac": sq["wave_cycles_waiting_frac"] if sq else None,
+                   "clock_ghz_in_kernel": round(g_sq / 8 / vals["_ns@SQ"], 3) if vals.get("_ns@SQ") else None,
+                   "source": "live rocprofv3 --pmc passes over the kernel alone: vector-ALU busy share, address-unit (TA) busy share, share of wave "
+                             "cycles spent waiting"}
+    return traffic, src, sq, binding
+
+
+def live_conv_counters(a, timeout_s=120):
+    """Matrix-pipe busy share and in-kernel clock of the convolution launches, from one --pmc pass over a short child run of this
+    same step (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs against GRBM_GUI_ACTIVE / 8 XCDs).  None when the pass fails."""
+    vals = _pmc_passes({"MFMA": ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]},
+                       ["--steps", "2", "--warmup", "1", "--workload", a.workload] + (["--frames", str(a.frames)] if a.frames else []),
+                       lambda k: "conv_mfma_kernel" in k, timeout_s)
+    g = vals.get("GRBM_GUI_ACTIVE")
+    if not g or "SQ_VALU_MFMA_BUSY_CYCLES" not in vals:
+        return None
+    return {"mfma_busy": round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (g / 8), 3),
+            "clock_ghz_in_kernel": round(g / 8 / vals["_ns@MFMA"], 3) if vals.get("_ns@MFMA") else None,
+            "source": "live rocprofv3 --pmc pass over this step: mean over all conv_mfma_kernel dispatches"}
+
+
+def _bound_label(binding, traffic, kern_ms):
+    """What binds the fused kernel according to the live counters: "hbm" only if its measured HBM traffic runs at more than half of the
+    peak rate; otherwise the busier of its two issue pipes, and "latency" when neither is above 85 % (waves waiting on dependent loads).
+    Without counters the label is "unmeasured" — never an assumed "hbm"."""
+    if traffic and kern_ms > 0 and traffic / (kern_ms * 1e-3) / 1e9 > 0.5 * HBM_PEAK_GBS:
+        return "hbm"
+    if not binding:
+        return "unmeasured (no counter pass in this run)"
+    v, t = binding.get("valu_busy") or 0.0, binding.get("ta_busy") or 0.0
+    pipe = "vector-memory address unit (L1 gather)" if t >= v else "vector-ALU issue"
+    return pipe if max(v, t) >= 0.85 else f"latency ({pipe} {max(v, t):.0%} busy, waves waiting {binding.get('wait_frac')})"
 
 
 def spawn_ranks(n: int, poll_s: float = 0.2, grace_s: float = 5.0) -> int:
@@ -252,12 +302,16 @@ def dry_run(a, rank, world):
     torch.manual_seed(1234 + rank)
     net = GNET(ch_in=256 + wl.D)
     bcast_bytes = mdist.broadcast_module_(net, src=0)
+    bcast_ok = mdist.broadcast_verified(net) if bcast_bytes else None
     fnet_bytes = 0
     if a.with_fnet:                                          # the shared F-Net weights north_star names: their own flat bucket(s)
         from types import SimpleNamespace
         from magnet_amd import fnet as mfnet
-        fnet_bytes = mdist.broadcast_module_(mfnet.FNET(SimpleNamespace(FNET_architecture="PSM-Net", FNET_feature_dim=wl.F)), src=0)
-    cpus = mdist.pin_to_cpu_slice(rank, world)
+        fnet = mfnet.FNET(SimpleNamespace(FNET_architecture="PSM-Net", FNET_feature_dim=wl.F))
+        fnet_bytes = mdist.broadcast_module_(fnet, src=0)
+        bcast_ok = bool(bcast_ok) and mdist.broadcast_verified(fnet)
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    cpus = mdist.pin_to_cpu_slice(local, int(os.environ.get("LOCAL_WORLD_SIZE", 0)) or world)
     n_cpus = mdist.gather_floats(float(len(cpus)))
     B = a.frames or 4
     lo, hi = mdist.shard_range(world * B, rank, world)
@@ -278,6 +332,8 @@ def dry_run(a, rank, world):
                           "config": {"workload": wl.name, "frames_per_step_all_ranks": int(frames),
                                      "parallelism": f"frames sharded over {world} rank(s); one weight broadcast ({bcast_bytes} B)"},
                           "weight_broadcast_bytes": bcast_bytes, "fnet_weight_broadcast_bytes": fnet_bytes,
+                          "rccl": {"world": world, "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                                   "broadcast_bytes": bcast_bytes + fnet_bytes, "broadcast_verified": bcast_ok},
                           "cpus_per_rank": [int(v) for v in n_cpus]}))
     mdist.barrier()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -327,7 +383,17 @@ def main():
 
     if os.environ.get("MAGNET_BENCH_FAIL_RANK") == os.environ.get("RANK", "0") and a.dry_run:
         raise SystemExit(3)                                  # launcher self-test (tests/test_bench_launcher.py): this rank dies early
-    rank, world, local = mdist.init_from_env(backend="gloo" if a.dry_run else None)
+    rccl = {"world": 1, "backend": None, "broadcast_bytes": 0, "broadcast_verified": None}
+    try:
+        # always a process group on a GPU — one rank included: RCCL initialisation and the weight broadcast run under the driver's N = 1
+        # clock exactly as they will at N = 8 (train_MaGNet.py:197-210)
+        rank, world, local = mdist.init_from_env(backend="gloo" if a.dry_run else None, always=a.dry_run or torch.cuda.is_available())
+    except Exception as e:                                   # a one-rank RCCL group that cannot be created must not take the N = 1 line down
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise
+        print(f"[bench] process-group initialisation failed ({type(e).__name__}: {e}); continuing single-process", file=sys.stderr)
+        rccl["error"] = f"{type(e).__name__}: {e}"[:200]
+        rank, world, local = 0, 1, 0
     if world != a.gpus and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if a.dry_run:
@@ -336,15 +402,16 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    cpus = mdist.pin_to_cpu_slice(local, world)               # one node: a contiguous CPU slice per rank (MAGNET_BENCH_AFFINITY=0: off)
-
     from magnet_amd import build as mbuild, lib
     if a.dev_lib:
         lib.use_dev_build()
     if rank == 0:
-        mbuild.build(dev=a.dev_lib)
+        mbuild.build(dev=a.dev_lib)                           # (a stale library is recompiled on all of the node's CPUs: pin afterwards)
     mdist.barrier()
     lib.load()
+    # one node: a contiguous CPU slice per LOCAL rank (MAGNET_BENCH_AFFINITY=0: off)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", 0)) or min(world, max(1, torch.cuda.device_count()))
+    cpus = mdist.pin_to_cpu_slice(local, local_world)
     from magnet_amd.homography import CostVolumeCW
     from magnet_amd.magnet import MAGNET
 
@@ -366,8 +433,18 @@ def main():
     model.fuse_conv_tail = not a.no_fuse_tail
     model.fuse_upsample = not a.no_fuse_upsample
     bcast_bytes = mdist.broadcast_module_(model, src=0)   # the one RCCL collective (weights), xGMI
+    bcast_ok = mdist.broadcast_verified(model, device=device) if bcast_bytes else None
 
+    # north_star: "RCCL-over-xGMI broadcast of shared F-Net weights": the 13.4 MB bucket travels in the default line too (the F-Net itself
+    # runs inside the step only with --with-fnet)
     fnet_bcast_bytes = 0
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and not a.with_fnet and not a.kernel_only:
+        from magnet_amd import fnet as mfnet_b
+        fa_b = make_args(wl, iters); fa_b.FNET_architecture = "PSM-Net"
+        fnet_b = mfnet_b.FNET(fa_b).to(device).eval()
+        fnet_bcast_bytes = mdist.broadcast_module_(fnet_b, src=0)
+        bcast_ok = bool(bcast_ok) and mdist.broadcast_verified(fnet_b, device=device)
+        del fnet_b
     inp = device_inputs(wl, B, seed=1000 + rank, device=device)
     k_list = model.k_list
     ev_pairs = []
@@ -387,6 +464,8 @@ def main():
         fa = make_args(wl, iters); fa.FNET_architecture = "PSM-Net"
         model.f_net = mfnet.FNET(fa).to(device).eval()
         fnet_bcast_bytes = mdist.broadcast_module_(model.f_net, src=0)   # the shared F-Net weights (13.4 MB): their own flat bucket(s)
+        if fnet_bcast_bytes:
+            bcast_ok = bool(bcast_ok) and mdist.broadcast_verified(model.f_net, device=device)
         model.d_net = _ResidentDNet(torch.cat([inp["ref_gmms"], inp["nghbr_gmms"]], dim=0),
                                     inp["x_d3"])          # the forward keeps x_d3[:B] only (MAGNET.py:139)
         model.fnet_mfma = True
@@ -501,9 +580,11 @@ def main():
     # HBM traffic and instruction counters of the fused kernel: measured LIVE by separate rocprofv3 --pmc passes over a
     # kernel-only child run of this same workload (rank 0, one GPU, production path only; null when the profiler is not
     # available or a pass fails — never a stored number)
-    traffic, traffic_src, pmc = None, None, None
+    traffic, traffic_src, pmc, binding, conv_binding = None, None, None, None, None
     if rank == 0 and world == 1 and not a.no_pmc and not a.kernel_only and a.path == 0:
-        traffic, traffic_src, pmc = live_counters(wl, B, fdt)
+        traffic, traffic_src, pmc, binding = live_counters(wl, B, fdt)
+        if a.conv_backend == "mfma" and not (a.graph or a.with_fnet):
+            conv_binding = live_conv_counters(a)
     alg_bytes = wl.algorithmic_bytes() * B
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     frames = world * B * a.steps
@@ -536,7 +617,9 @@ def main():
                         + ("the bf16x3 MFMA kernel" if a.conv_backend == "mfma" else "MIOpen fp32")),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; "
                                       f"one RCCL weight broadcast ({bcast_bytes} B)"},
-            "roofline": {"bound": "hbm", "kernel": "fused sample+warp+score (magnet_cost_volume_cw)",
+            # `frac` is against the HBM roofline (the contract's target); `bound` says what the counters say binds the kernel
+            "roofline": {"bound": _bound_label(binding, traffic, kern_ms), "contract_roofline": "hbm",
+                         "kernel": "fused sample+warp+score (magnet_cost_volume_cw)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
@@ -546,12 +629,16 @@ def main():
             "ms_per_step_inputs_in_kernel_layouts": packed_ms,
             "frames_per_s_inputs_in_kernel_layouts": (world * B / (packed_ms * 1e-3)) if packed_ms else None,
             "weight_broadcast_bytes": bcast_bytes, "fnet_weight_broadcast_bytes": fnet_bcast_bytes,
+            "rccl": dict(rccl, world=world, backend=(torch.distributed.get_backend() if torch.distributed.is_available() and torch.distributed.is_initialized() else None),
+                         broadcast_bytes=bcast_bytes + fnet_bcast_bytes, broadcast_verified=bcast_ok),
             "cpus_per_rank": len(cpus),
             "per_rank_frames_per_s": per_rank,
             "per_rank_min_max": [min(per_rank), max(per_rank)],
         }
         if pmc:
             res["roofline"]["sq_counters"] = pmc            # instructions per (pixel, view), wait fraction: measured in this run
+        if binding:
+            res["roofline"]["binding"] = binding
         if c3:
             t3 = sum(t for t, _ in c3) / len(c3); f3 = sum(f for _, f in c3) / len(c3)
             res["roofline_conv"] = {
@@ -562,6 +649,8 @@ def main():
                         "executes 3 bf16 MFMAs per product term, so matrix-pipe utilisation is 3x this fraction",
                 "algorithmic_flops_per_launch": f3, "avg_launch_ms": t3, "launches_timed": len(c3),
                 "all_conv_layers_ms_per_step": conv_ms_all}
+            if conv_binding:
+                res["roofline_conv"].update(conv_binding)
         if model_cpu is not None:
             res["cpu_baseline"] = cpu_baseline(wl, model_cpu, iters)
         print(json.dumps(res))

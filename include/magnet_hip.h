@@ -41,7 +41,12 @@ extern "C" {
 
 #define MAGNET_API __attribute__((visibility("default")))
 
-#define MAGNET_HIP_VERSION 302            /* major*10000 + minor*100 + patch */
+#define MAGNET_HIP_VERSION 400            /* major*10000 + minor*100 + patch.
+                                           * BINARY COMPATIBILITY: the argument structs below carry no size field and have grown at their END between versions
+                                           * (MagnetConvArgs: v300 up_*, v301 gu_*, v302 in_sc / w_sc / sc_rows).  A caller must be compiled against the header whose
+                                           * MAGNET_HIP_VERSION equals magnet_version() of the library it loads, and must check that at load time (INTEGRATION.md;
+                                           * magnet_amd/lib.py mirrors the structs field for field and tests/test_abi.py compares the layouts with a gcc probe).
+                                           * From v400 on a struct change bumps the MINOR number, never only the patch. */
 
 enum {                                     /* storage dtype of channel-last feature maps */
     MAGNET_FEAT_F32  = 0,
@@ -96,7 +101,10 @@ typedef struct MagnetCostVolumeArgs {
                                                   differs from the reference's by its normalise / unnormalise rounding (<= 1.5e-5
                                                   texel), so on features that vary strongly from texel to texel (white noise) the
                                                   plain 2e-5 + 2e-5|c| bound alone does NOT hold; on smooth features it does
-                                                  (tests/test_gpu_fast_matcher.py);
+                                                  (tests/test_gpu_fast_matcher.py).  Downstream of the volume, north_star's bar — depth abs_rel
+                                                  < 1e-4 against the reference loop — holds with a measured worst case of 2.2e-5 (C3 shape,
+                                                  bf16 feature storage, I = 3, production matcher + matrix-core convolutions against the
+                                                  oracle loop; 8e-8 .. 2.8e-7 against the reference's own forward on its fixtures G6 / G13);
                                               1 = generic gather kernel (bit-exact reference arithmetic, slow);
                                               2 = exact candidate-lane kernel (the reference's fp32 geometry to the bit) or MAGNET_E_SHAPE;
                                               3 = exact pixel-lane worklist kernel or MAGNET_E_SHAPE;
@@ -267,7 +275,9 @@ typedef struct MagnetConvArgs {
      * in_sc [cin / 32][sc_rows] uint32 {e_h + 127, e_l + 127, 0, 0} per (block, row), w_sc [taps][cin / 32][cout_pad] uint32 likewise per
      * (tap, block, output channel).  magnet_pack_mx writes the activation planes; magnet_amd/convnet.py prepares the weights.  The kernel
      * runs hi*hi on the fp16 matrix instruction and lo*hi + hi*lo on the block-scaled fp8 one (x*w to ~1e-5 relative, as the bf16x3 form):
-     * 2 matrix-pipe units per product term instead of 3.  NULL / 0 = the bf16x3 format described above. */
+     * 2 matrix-pipe units per product term instead of 3.  NULL / 0 = the bf16x3 format described above.
+     * DOMAIN of this format: |x| <= 65504 (the fp16 plane); magnet_pack_mx clamps larger magnitudes to +-65504 (the bf16x3 format has no
+     * such limit).  `bias` is read with 16-byte loads in every format: 16-byte aligned, as all pointers of this struct. */
     const void  *in_sc, *w_sc;
     int64_t      sc_rows;
 } MagnetConvArgs;                          /* out_mode 2: one bf16 plane (round-to-nearest-even) at out_hi */

@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmagnet_hip.so")
 DEV_LIB = os.path.join(HERE, "libmagnet_hip_dev.so")      # -DMAGNET_DEV build, loaded only by tools/ (lib.use_dev_build())
-SOURCES = ["api.hip", "cost_volume.hip", "cost_volume_worklist.hip", "cost_volume_cand.hip", "cost_volume_fast.hip", "cost_volume_fast64.hip", "cost_volume_v3.hip", "cost_volume_v4.hip", "cost_volume_v5.hip", "cost_volume_f_bwd.hip", "cost_volume_f_gather.hip", "conv_mfma.hip", "fnet_kernels.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "cost_volume.hip", "cost_volume_worklist.hip", "cost_volume_cand.hip", "cost_volume_fast.hip", "cost_volume_fast64.hip", "cost_volume_v3.hip", "cost_volume_f_bwd.hip", "cost_volume_f_gather.hip", "conv_mfma.hip", "fnet_kernels.hip", "elementwise.hip"]
+DEV_SOURCES = ["cost_volume_v4.hip", "cost_volume_v5.hip"]     # round 4's measured-and-lost matcher experiments: records, compiled into the dev library only
 HEADERS = ["cv_common.hpp", "cv_fast_common.hpp", "cv_runs.hpp", "conv_common.hpp", "warp_math.hpp", os.path.join("..", "..", "include", "magnet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fvisibility=hidden",
@@ -33,7 +34,7 @@ def _stale(lib: str = LIB) -> bool:
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + (DEV_SOURCES if lib == DEV_LIB else []) + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -53,7 +54,7 @@ def build(force: bool = False, verbose: bool = False, dev: bool | None = None) -
         return DEV_LIB if dev else LIB
     objs = []
     procs = []
-    for s in SOURCES:
+    for s in SOURCES + (DEV_SOURCES if dev else []):
         o = os.path.join(CSRC, s.replace(".hip", ".dev.o" if dev else ".o"))
         cmd = [hipcc(), *FLAGS, *(["-DMAGNET_DEV"] if dev else []), *EXTRA_FLAGS.get(s, []), "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:

@@ -149,7 +149,6 @@ class ConvStackMFMA:
         return out
 
     @torch.no_grad()
-    @torch.no_grad()
     def packed_mx(self, device):
         """First layer's weights in the fp16 + e4m3 operand format (conv_mfma.hip, WIN == 4 loop): (w_f16 (taps, cout_pad, cin), w_qr
         (taps, cout_pad, cin) int16 container, w_sc (taps, cin / 32, cout_pad) int32)."""
@@ -161,6 +160,7 @@ class ConvStackMFMA:
             self._mx, self._mx_key = dict(w_hi=hi, w_lo=qr, w_sc=sc.permute(0, 2, 1).contiguous()), key
         return self._mx
 
+    @torch.no_grad()
     def packed_first_split(self, device, n_var, inv_off):
         """First layer split by input channels of the (padded) input buffer: channels [0, n_var) vary per refinement
         iteration (the cost volume), channels [inv_off, cin_pad) are loop-invariant (x_d3), everything between is padding.

@@ -290,7 +290,7 @@ MAGNET_API int magnet_conv_mfma(const MagnetConvArgs* a, void* stream) {
     if (a->taps != 1 && a->wp < 3) return fail(MAGNET_E_DIM, "magnet_conv_mfma: wp (row pitch of the bordered grid) missing");
     if (!((a->cout_pad > 0 && a->cout_pad % 128 == 0) || a->cout_pad == 144 || a->cout_pad == 16 || a->cout_pad == 32 || a->cout_pad == 64))
         return fail(MAGNET_E_DIM, "magnet_conv_mfma: cout_pad=%d unsupported (multiple of 128, or 144, 64, 32, 16)", a->cout_pad);
-    if (!aligned16(a->in_hi) || !aligned16(a->in_lo) || !aligned16(a->w_hi) || !aligned16(a->w_lo) ||
+    if (!aligned16(a->in_hi) || !aligned16(a->in_lo) || !aligned16(a->w_hi) || !aligned16(a->w_lo) || !aligned16(a->bias) ||
         (!tail && (a->out_mode == 0 ? (!aligned16(a->out_hi) || !aligned16(a->out_lo)) : (a->out_mode == 1 ? !aligned16(a->out_f32) : !aligned16(a->out_hi)))))
         return fail(MAGNET_E_ALIGN, "magnet_conv_mfma: pointers must be 16-byte aligned");
     if (a->dil < 0 || a->dil > 8) return fail(MAGNET_E_DIM, "magnet_conv_mfma: dil=%d out of range", a->dil);

@@ -2100,7 +2100,9 @@ __global__ __launch_bounds__(256) void pack_mx_kernel(const float* __restrict__ 
     uint32_t hw16[16];
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
-        const float xv = tile[pw_idx(blk * 32 + c, q)];
+        // domain of the format: |x| <= 65504 (the fp16 plane); larger magnitudes are clamped — an Inf in the fp16 plane would make the
+        // residual -Inf and poison the block exponent (the bf16x3 format has no such limit; include/magnet_hip.h states the domain)
+        const float xv = __builtin_amdgcn_fmed3f(tile[pw_idx(blk * 32 + c, q)], -65504.0f, 65504.0f);
         const _Float16 hh = (_Float16)xv;
         hi[c] = (float)hh; lo[c] = xv - hi[c];
         mh = fmaxf(mh, fabsf(hi[c])); ml = fmaxf(ml, fabsf(lo[c]));

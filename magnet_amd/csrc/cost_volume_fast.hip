@@ -21,10 +21,6 @@
 // Instruction diet relative to cost_volume_cand.hip (per (pixel, view) wave-iteration, bf16 F = 64, D = 64):
 //   * frame / view base addresses are wave-uniform (readfirstlane) -> scalar address arithmetic, 32-bit lane offsets
 //   * (mu,sigma) taps: every lane loads its own 2 x 16 B (no leader election, no ds_bpermute)
-//   * bf16 features with D >= 64: the (item, tap) x channel contraction runs on the MATRIX pipe:
-//     v_mfma_f32_16x16x32_bf16 with A = 16 (item, tap) units x 32 channels, B = the pixel's reference vector in all
-//     16 columns (1/16 of the tile is useful, but the matrix pipe is otherwise idle here and its result layout is exactly
-//     "lane group g = item g, register t = tap t"): no v_dot2c, no DPP reduction
 //   * no fp64, no exec-mask branches around the gate / combine
 // Everything that needs the reference's exact rounding (explicit d_volume, est_costvolume_F mode, stats) stays in
 // cost_volume_cand.hip / cost_volume.hip.
@@ -32,22 +28,26 @@
 
 namespace magnet {
 
+// Round 5: TEXEL-PAIR ITEMS (TX; see cost_volume_fast64.hip's header).  An item is a pair of texels across the direction in which the
+// candidates of a (pixel, view) travel through the source map; a run's quad is two consecutive pairs, and a leader whose quad is the
+// previous run's quad moved one step along the direction of travel re-uses that run's second pair.  Here several pixels share a wave
+// (D <= 32), so mode and direction are per-lane values and the pairs are numbered in travel order (the combine mirrors its
+// interpolation weight for a segment travelling towards smaller coordinates).
+//
 // DL   = candidates per pixel group inside a wave (8,16,32,64); PPW = 64/DL pixels per iteration
 // CPL  = 16-byte channel chunks per lane in the VALU correlation (F*sizeof(FeatT)/16 <= LPU*CPL), FULL = exactly
-// MINW = waves per SIMD to compile for; LPU = lanes per (item, tap) unit of the VALU correlation
-// OPT  = bit 0: correlation on the matrix pipe (bf16, DL = 64, F = 32*KS); bit 1: write gate bits (debug / parity tests)
-// KS   = K steps of 32 channels of the MFMA correlation
-template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU, int OPT, int KS>
+// MINW = waves per SIMD to compile for; LPU = lanes per texel of the VALU correlation
+// OPT  = bit 1: write gate bits (debug / parity tests); bit 2: texel-pair items (the product form; quad items are kept for dev A/B)
+template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU, int OPT>
 __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
-    constexpr bool MFMA = (OPT & 1) != 0;
     constexpr bool GBITS = (OPT & 2) != 0;
-    constexpr bool NOGMM = (OPT & 4) != 0;               // dev timing ablation: no (mu,sigma) taps, pseudo gate
-    constexpr bool NOCORR = (OPT & 8) != 0;              // dev timing ablation: no feature loads / dot products
-    constexpr bool LEAD = (OPT & 16) != 0;               // (mu,sigma) taps loaded by the first lane of each run of equal quads, shared through LDS
-    constexpr int IPP = MFMA ? 4 : 64 / (4 * LPU);        // items per correlation pass
+    constexpr bool TX = (OPT & 4) != 0;
+    constexpr int TPI = TX ? 2 : 4;                       // texels per item
+    constexpr int IPP = 64 / (TPI * LPU);                 // items per correlation pass
     constexpr int CSTR = LPU * 16;                        // byte stride between a lane's channel chunks (VALU correlation)
     constexpr int PPW = 64 / DL;
-    static_assert(!MFMA || (PPW == 1 && sizeof(FeatT) == 2), "MFMA correlation: bf16 features, one pixel per wave iteration");
+    constexpr int CT_BYTES = TX ? (128 + 2) * 8 : 16 + 1024;          // TX: [2 zero pairs | 128 pairs] x {c0, c1}; else [zero | 64 items] x 4 taps
+    constexpr int IT_BYTES = TX ? (128 + 2) * 8 : 272;                // TX: {byte offset of texel 0, of texel 1} (+ pixel in the low bits); else texel index (+ pixel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -72,14 +72,16 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
     // Round 3: only the 8 pixels the next iterations work on are staged (re-staged once in the middle of the wave's 16): with 16 the
     // fp32 instances sat at 5 workgroups per CU by LDS, and the path is occupancy-sensitive (capped at 4 / 3: +11 % / +36 % time)
     const int ref_lds = PPW > 1 ? 8 * (int)texel_bytes : 0;
-    const int wave_bytes = p.V * 512 + 16 + 1024 + 272 + out_bytes + (LEAD ? 2048 + 32 : 0) + ref_lds;
+    const int md_bytes = TX ? p.V * 64 : 0;
+    const int wave_bytes = p.V * 512 + CT_BYTES + IT_BYTES + out_bytes + md_bytes + ref_lds;
     unsigned char* wbase = smem + wv * wave_bytes;
     unsigned char* refl = wbase + (wave_bytes - ref_lds);                             // [8 px][texel_bytes]
     float4*   pvtab = reinterpret_cast<float4*>(wbase);                               // [V][16 px][2]
-    float4*   ctab  = reinterpret_cast<float4*>(wbase + p.V * 512);                   // [zero slot for closed lanes | 64 items] x 4 taps
-    uint32_t* items = reinterpret_cast<uint32_t*>(wbase + p.V * 512 + 16 + 1024);     // [64 + pad]
-    float*    outb  = reinterpret_cast<float*>(wbase + p.V * 512 + 16 + 1024 + 272);  // [OUT_PX][DL] results of one block
-    float4*   gslot = reinterpret_cast<float4*>(wbase + p.V * 512 + 16 + 1024 + 272 + out_bytes);   // LEAD: [1 + 64 runs][2] taps
+    float4*   ctab  = reinterpret_cast<float4*>(wbase + p.V * 512);                   // quad items: [zero slot for closed lanes | 64 items] x 4 taps
+    float2*   ctab2 = reinterpret_cast<float2*>(wbase + p.V * 512);                   // pair items: [2 zero slots | 128 pairs] x 2 texels
+    uint32_t* items = reinterpret_cast<uint32_t*>(wbase + p.V * 512 + CT_BYTES);      // quad items: [64 + pad]; pair items: [128 + pad] x 2
+    float*    outb  = reinterpret_cast<float*>(wbase + p.V * 512 + CT_BYTES + IT_BYTES);   // [OUT_PX][DL] results of one block
+    uint32_t* mtab  = reinterpret_cast<uint32_t*>(wbase + p.V * 512 + CT_BYTES + IT_BYTES + out_bytes);   // TX: [V][16 px] travel mode | signed step << 2
 
     // ---- depth-linear projection terms for the wave's 16 pixels x V views (once per tile row) ----
     for (int e = lane; e < 16 * p.V; e += 64) {
@@ -90,8 +92,14 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
         const PixelView pv = make_pixel_view(p.intM + (size_t)b * 9, p.poses + ((size_t)b * p.V + v) * 16, r0, r1, r2);
         pvtab[e * 2 + 0] = make_float4(pv.rpx, pv.rpy, pv.rpz, pv.rcz);
         pvtab[e * 2 + 1] = make_float4(pv.kt0, pv.kt1, pv.kt2, pv.tz);
+        if (TX) {
+            const uint32_t md = travel_mode(pv);
+            const int step = ((md & 1u) ? Wp : 1) * ((md & 2u) ? -1 : 1);             // key of the next quad along the direction of travel - this quad's key
+            mtab[e] = md | ((uint32_t)step << 2);
+        }
     }
-    if (lane == 0) ctab[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (TX) { if (lane < 2) ctab2[lane] = make_float2(0.f, 0.f); }
+    else if (lane == 0) ctab[0] = make_float4(0.f, 0.f, 0.f, 0.f);
     fwave_lds_fence();
 
     const int nchunk = (int)(texel_bytes / 16);
@@ -100,11 +108,9 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
     const uint32_t xlim = __float_as_uint((float)(p.w + 1)), ylim = __float_as_uint((float)(p.h + 1));
     // lane roles
     const int g = lane / DL, j0 = lane % DL;                                      // geometry: pixel group, candidate
-    // correlation, VALU form: chunk, tap, item of the pass.  MFMA form: A row = lane & 15 = (item of the pass, tap), K slot = lane >> 4
-    const int sub = MFMA ? (lane >> 4) : (lane & (LPU - 1));
-    const int tap = MFMA ? (lane & 3) : ((lane / LPU) & 3);
-    const int upair = MFMA ? ((lane & 15) >> 2) : (lane / (4 * LPU));
-    const uint32_t lane_src_off = (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes + (uint32_t)sub * 16u;
+    const int sub = lane & (LPU - 1), tap = (lane / LPU) & (TPI - 1), upair = lane / (TPI * LPU);   // correlation: chunk, texel of the item, item of the pass
+    const uint32_t lane_src_off = (TX ? 0u : (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes) + (uint32_t)sub * 16u;
+    const uint32_t row_bytes = (uint32_t)Wp * texel_bytes;
     const unsigned char* __restrict__ ref_row = reinterpret_cast<const unsigned char*>(p.ref_feat) +
         ((size_t)b * hw + (size_t)yc * p.w) * texel_bytes;                        // reference features of this pixel row
     const float invV = 1.0f / (float)p.V;
@@ -146,15 +152,14 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
             const int q = qb * PPW + g;                                           // pixel within the wave's row
             const int x = x_base + q;
             const bool live = (x < p.w) && (y < p.h) && (j < p.D);
-            // PPW == 1: every correlation unit of this iteration belongs to this one pixel: its reference vector stays in
-            // registers for all views (VALU form: the lane's chunk(s); MFMA form: the B fragments, same vector in all 16 columns)
-            uint4 rvp[MFMA ? KS : CPL];
+            // PPW == 1: every correlation unit of this iteration belongs to this one pixel: its reference vector (the lane's chunks)
+            // stays in registers for all views
+            uint4 rvp[CPL];
             if (PPW == 1) {
                 const unsigned char* rp = ref_row + (__umul24((uint32_t)min(x, p.w - 1), texel_bytes) + (uint32_t)sub * 16u);
 #pragma unroll
-                for (int cc = 0; cc < (MFMA ? KS : CPL); ++cc)
-                    rvp[cc] = (MFMA || FULL || (sub + LPU * cc < nchunk)) ? *reinterpret_cast<const uint4*>(rp + cc * (MFMA ? 64 : CSTR))
-                                                                          : make_uint4(0, 0, 0, 0);
+                for (int cc = 0; cc < CPL; ++cc)
+                    rvp[cc] = (FULL || (sub + LPU * cc < nchunk)) ? *reinterpret_cast<const uint4*>(rp + cc * CSTR) : make_uint4(0, 0, 0, 0);
             }
             float d;
             {
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                 const cvr_gptr sgm = (cvr_gptr)(unsigned long long)v4_uniform_ptr((const void*)(sgm_b + (size_t)v * sgm_vstride));
                 // ---------------- geometry ----------------
                 const float4 pa = pvtab[(v * 16 + q) * 2 + 0], pb = pvtab[(v * 16 + q) * 2 + 1];
+                const uint32_t md = TX ? mtab[v * 16 + q] : 0u;
                 const float Px = __builtin_fmaf(pa.x, d, pb.x);                  // homography.py:132
                 const float Py = __builtin_fmaf(pa.y, d, pb.y);
                 const float Pz = __builtin_fmaf(pa.z, d, pb.z);
@@ -186,29 +192,13 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                 const bool inwin = (__float_as_uint(ixs) < xlim) && (__float_as_uint(iys) < ylim);
                 const uint32_t qi = inwin ? (uint32_t)__mul24((int)y0f, Wp) + (uint32_t)(int)x0f : 0u;   // quad origin, padded map
                 // ---------------- (mu,sigma) taps + consistency gate ----------------
-                float4 g0 = make_float4(0.f, 1.f, 0.f, 1.f), g1 = g0;
-                if (LEAD) {
-                    const uint32_t tkey = inwin ? qi : FKEY_CLOSED;
-                    const uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);
-                    const bool lead = inwin && (tkey != tprev);
-                    const unsigned long long lbal = __builtin_amdgcn_ballot_w64(lead);
-                    const int run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lbal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lbal, lead ? 1u : 0u));
-                    if (lead) {
-                        gslot[run * 2 + 0] = v3_gld_f4(sgm + qi * 8u);
-                        gslot[run * 2 + 1] = v3_gld_f4(sgm + (qi + (uint32_t)Wp) * 8u);
-                    }
-                    fwave_lds_fence();
-                    g0 = gslot[run * 2 + 0]; g1 = gslot[run * 2 + 1];
-                } else if (!NOGMM) {
-                    g0 = v3_gld_f4(sgm + qi * 8u);                 // (mu,sg) x0, x0+1 of row y0
-                    g1 = v3_gld_f4(sgm + (qi + (uint32_t)Wp) * 8u);
-                }
+                const float4 g0 = v3_gld_f4(sgm + qi * 8u);                      // (mu,sg) x0, x0+1 of row y0
+                const float4 g1 = v3_gld_f4(sgm + (qi + (uint32_t)Wp) * 8u);
                 float mu_w = g0.x * wnw, sg_w = g0.y * wnw;
                 mu_w = __builtin_fmaf(g0.z, wne, mu_w); sg_w = __builtin_fmaf(g0.w, wne, sg_w);
                 mu_w = __builtin_fmaf(g1.x, wsw, mu_w); sg_w = __builtin_fmaf(g1.y, wsw, sg_w);
                 mu_w = __builtin_fmaf(g1.z, wse, mu_w); sg_w = __builtin_fmaf(g1.w, wse, sg_w);
-                bool gate = inwin && (__builtin_fabsf(zw - mu_w) < sg_w * kappa);                // homography.py:157-158
-                if (NOGMM) gate = inwin && ((j0 & 7) < 5) && (zw > sg_w);
+                const bool gate = inwin && (__builtin_fabsf(zw - mu_w) < sg_w * kappa);          // homography.py:157-158
                 if (GBITS && live)
                     p.gate_bits[(((size_t)b * p.V + v) * p.D + j) * hw + (size_t)y * p.w + x] = gate ? 1 : 0;
 
@@ -219,34 +209,36 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                 const bool fresh = gate && (key != prev);
                 const unsigned long long bal = __builtin_amdgcn_ballot_w64(fresh);
                 if (bal == 0ull) continue;                                        // wave-uniform: nothing open in this view
-                const int nitems = __popcll(bal);
-                const int incl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                      __builtin_amdgcn_mbcnt_lo((uint32_t)bal, fresh ? 1u : 0u));   // items at or below this lane
-                if (fresh) items[incl - 1] = PPW == 1 ? qi : (((uint32_t)q << 26) | qi);
-                if (lane == 0) items[nitems] = 0u;                                // pad to a whole pass: pixel 0, texel 0
+                int nitems = __popcll(bal);
+                int incl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                __builtin_amdgcn_mbcnt_lo((uint32_t)bal, fresh ? 1u : 0u));         // leaders at or below this lane
+                float fmin = 0.f, fmaj = 0.f;
+                if (TX) {
+                    const bool rowm = (md & 1u) != 0, neg = (md & 2u) != 0;
+                    // a leader whose quad is the previous run's quad moved one step along the direction of travel shares that run's
+                    // second pair (FKEY_CLOSED + a step is no valid key)
+                    const bool shr = fresh && (prev + (uint32_t)((int)md >> 2) == key);
+                    const unsigned long long sbal = __builtin_amdgcn_ballot_w64(shr);
+                    const int ns = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sbal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sbal, shr ? 1u : 0u));
+                    nitems = 2 * nitems - __popcll(sbal);                         // pairs of this view
+                    incl = 2 * (incl - 1) - ns;                                   // the lane's first pair, numbered in travel order
+                    const uint32_t oJ = rowm ? row_bytes : texel_bytes, oM = rowm ? texel_bytes : row_bytes;
+                    const uint32_t o0 = __umul24(qi, texel_bytes) + (PPW > 1 ? (uint32_t)(q & 7) : 0u);   // (the pixel -> its reference vector in LDS)
+                    const uint32_t oF = o0 + (neg ? oJ : 0u), oS = o0 + (neg ? 0u : oJ);           // first / second pair in travel order
+                    if (fresh && !shr) *reinterpret_cast<uint2*>(items + incl * 2) = make_uint2(oF, oF + oM);
+                    if (fresh) *reinterpret_cast<uint2*>(items + (incl + 1) * 2) = make_uint2(oS, oS + oM);
+                    if (lane == 0) *reinterpret_cast<uint2*>(items + nitems * 2) = make_uint2(0u, 0u);   // pad to a whole pass: pixel 0, texel 0
+                    incl = gate ? incl + 2 : 0;                                   // closed lanes: the zero pairs
+                    fmin = rowm ? bx : by; fmaj = rowm ? by : bx;
+                    fmaj = neg ? 1.0f - fmaj : fmaj;                              // pairs are numbered in travel order
+                } else {
+                    if (fresh) items[incl - 1] = PPW == 1 ? qi : (((uint32_t)q << 26) | qi);
+                    if (lane == 0) items[nitems] = 0u;                            // pad to a whole pass: pixel 0, texel 0
+                }
                 fwave_lds_fence();
 
                 // ---------------- correlation ----------------
-                if (NOCORR) {
-                } else if (MFMA) {
-                    // rows of A = (item of the pass, tap); B = the pixel's reference vector in every column: lane group g4 = lane >> 4
-                    // ends up with C[reg t] = <ref, src[item g4, tap t]>
-                    for (int ps = 0; ps < nitems; ps += 4) {
-                        const uint32_t item = items[min(ps + upair, nitems)];
-                        const cvr_gptr sp = src + (__umul24(item, texel_bytes) + lane_src_off);
-                        uint4 av[KS];
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks) av[ks] = v3_gld_u4(sp + ks * 64);
-                        ff32x4_t c4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks)
-                            c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(fbf16x8_t, av[ks]),
-                                                                         __builtin_bit_cast(fbf16x8_t, rvp[ks]), c4, 0, 0, 0);
-                        const int it = ps + (lane >> 4);
-                        if ((lane & 15) == 0 && it < nitems)
-                            ctab[it + 1] = make_float4(c4[0], c4[1], c4[2], c4[3]);
-                    }
-                } else {
+                {
                     const int passes = (nitems + IPP - 1) / IPP;
                     for (int ps = 0; ps < passes; ps += 2) {
                         uint4 sv[2][CPL], rv[2][CPL];
@@ -255,9 +247,9 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                         for (int a = 0; a < 2; ++a) {
                             if (a == 1 && !second) break;
                             const int it = min(IPP * (ps + a) + upair, nitems);   // tail of the last pass: the pad item
-                            const uint32_t item = items[it];
-                            const cvr_gptr sp = src + (__umul24(item & 0xffffffu, texel_bytes) + lane_src_off);
-                            const unsigned char* rp = refl + (__umul24((item >> 26) & 7u, texel_bytes) + (uint32_t)sub * 16u);   // LDS (PPW > 1 only)
+                            const uint32_t item = TX ? items[it * 2 + tap] : items[it];
+                            const cvr_gptr sp = src + ((TX ? (item & ~15u) : __umul24(item & 0xffffffu, texel_bytes)) + lane_src_off);
+                            const unsigned char* rp = refl + (__umul24(TX ? (item & 7u) : ((item >> 26) & 7u), texel_bytes) + (uint32_t)sub * 16u);   // LDS (PPW > 1 only)
 #pragma unroll
                             for (int cc = 0; cc < CPL; ++cc) {
                                 const bool okc = FULL || (sub + LPU * cc < nchunk);
@@ -274,14 +266,22 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
                             for (int cc = 0; cc < CPL; ++cc) part = fdot_chunk(rv[a][cc], sv[a][cc], part, FeatT());
                             part = LPU == 8 ? freduce8(part) : freduce4(part);
                             const int it = IPP * (ps + a) + upair;
-                            if (sub == 0 && it < nitems) reinterpret_cast<float*>(ctab + it + 1)[tap] = part;
+                            if (sub == 0 && it < nitems) {
+                                if (TX) reinterpret_cast<float*>(ctab2 + it + 2)[tap] = part;
+                                else reinterpret_cast<float*>(ctab + it + 1)[tap] = part;
+                            }
                         }
                     }
                 }
                 fwave_lds_fence();
 
                 // ---------------- bilinear combine + view accumulation ----------------
-                {
+                if (TX) {
+                    const float2 cA = ctab2[incl], cB = ctab2[incl + 1];
+                    const float t = __builtin_fmaf(fmin, cA.y - cA.x, cA.x), l = __builtin_fmaf(fmin, cB.y - cB.x, cB.x);
+                    const float c = __builtin_fmaf(fmaj, l - t, t);               // homography.py:150,155 (grid_sample's bilinear weights, factored)
+                    acc += gate ? c : 0.f;                                        // homography.py:159,116 (fp32 here); the fractions of a closed lane may be NaN
+                } else {
                     const float4 c4 = ctab[gate ? incl : 0];                      // closed lanes: the zero slot
                     float c = c4.x * wnw;
                     c = __builtin_fmaf(c4.y, wne, c);
@@ -322,21 +322,22 @@ __global__ __launch_bounds__(256, MINW) void cv_fast_kernel(const CvParams p) {
 }
 
 template <int DL>
-static size_t fast_lds_bytes(const CvParams& p) {
-    return (size_t)4 * (p.V * 512 + 16 + 1024 + 272 + (p.cost_hi ? 0 : 8 * DL * 4) + (DL < 64 ? 8 * p.F * (p.feat_bf16 ? 2 : 4) : 0));
+static size_t fast_lds_bytes(const CvParams& p, bool tx = true) {
+    const size_t tables = tx ? (size_t)(130 * 8 + 130 * 8 + p.V * 64) : (size_t)(16 + 1024 + 272);
+    return (size_t)4 * (p.V * 512 + tables + (p.cost_hi ? 0 : 8 * DL * 4) + (DL < 64 ? 8 * p.F * (p.feat_bf16 ? 2 : 4) : 0));
 }
 
-template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU, int MF, int KS>
+template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU>
 static hipError_t launch_fast(const CvParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
-    if constexpr (DL == 64 && sizeof(FeatT) == 2 && KS <= 2 && FULL) {                      // dev timing variants (C2 shape only)
-        const int dv = (p.ablate >> 1) & 0xf;                                                 // path bits 9..12
-        const size_t lds = fast_lds_bytes<DL>(p);
-        if (dv == 1) { hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 4, KS>), grid, block, lds, stream, p); return hipGetLastError(); }
-        if (dv == 2) { hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 8, KS>), grid, block, lds, stream, p); return hipGetLastError(); }
-        if (dv == 3) { hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 12, KS>), grid, block, lds, stream, p); return hipGetLastError(); }
-        if (dv == 8) { hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 16, KS>), grid, block, lds + 4 * 2080, stream, p); return hipGetLastError(); }
+#ifdef MAGNET_DEV
+    if (p.ablate & 0x400) {                                                       // dev: quad items (rounds 2 - 4) for same-box A/B
+        const size_t lq = fast_lds_bytes<DL>(p, false);
+        if (p.gate_bits) hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, 2>), grid, block, lq, stream, p);
+        else hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, 0>), grid, block, lq, stream, p);
+        return hipGetLastError();
     }
+#endif
     size_t lds = fast_lds_bytes<DL>(p);
 #ifdef MAGNET_DEV
     {   // dev: cap the workgroups per CU by asking for more LDS than the kernel uses (occupancy sensitivity)
@@ -344,34 +345,33 @@ static hipError_t launch_fast(const CvParams& p, hipStream_t stream) {
         if (cap) { const size_t need = (size_t)160 * 1024 / (cap + 1) + 512; if (lds < need) lds = need; }
     }
 #endif
-    if (p.gate_bits) hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF | 2, KS>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, MF, KS>), grid, block, lds, stream, p);
+    if (p.gate_bits) hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, 6>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, 4>), grid, block, lds, stream, p);
     return hipGetLastError();
 }
 
-template <typename FeatT, int CPL, bool FULL, int LPU, int MF, int KS>
+template <typename FeatT, int CPL, bool FULL, int LPU>
 static hipError_t launch_fast_c(const CvParams& p, hipStream_t stream) {
-    if (p.D <= 8)       return launch_fast<FeatT, 8, CPL, FULL, 4, LPU, 0, 1>(p, stream);
-    else if (p.D <= 16) return launch_fast<FeatT, 16, CPL, FULL, 4, LPU, 0, 1>(p, stream);
-    else if (p.D <= 32) return launch_fast<FeatT, 32, CPL, FULL, 4, LPU, 0, 1>(p, stream);
-    if constexpr (sizeof(FeatT) == 4) return launch_fast<FeatT, 64, CPL, FULL, 6, LPU, 0, 1>(p, stream);
-    else return launch_fast<FeatT, 64, CPL, FULL, 8, LPU, MF, KS>(p, stream);
+    if (p.D <= 8)       return launch_fast<FeatT, 8, CPL, FULL, 4, LPU>(p, stream);
+    else if (p.D <= 16) return launch_fast<FeatT, 16, CPL, FULL, 4, LPU>(p, stream);
+    else if (p.D <= 32) return launch_fast<FeatT, 32, CPL, FULL, 4, LPU>(p, stream);
+    if constexpr (sizeof(FeatT) == 4) return launch_fast<FeatT, 64, CPL, FULL, 6, LPU>(p, stream);
+    else return launch_fast<FeatT, 64, CPL, FULL, 6, LPU>(p, stream);          // (8 waves per SIMD needed scratch)
 }
 
 // Production matcher: fused candidate sampling only (no explicit d_volume), mode 0, no stats counters.
 hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled) {
     *handled = false;
     if (p.d_volume || p.mode_f || p.stats) return hipSuccess;
-    const bool have_gmm = p.src_gmm != nullptr;               // the round-2 kernels below read the interleaved map
+    const bool have_gmm = p.src_gmm != nullptr;               // the kernels below read the interleaved map
     const size_t esz = p.feat_bf16 ? 2 : 4;
     if ((size_t)(p.h + 2) * (p.w + 2) >= ((size_t)1 << 24)) return hipSuccess;               // 24-bit texel index
     if ((size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets
     if (fast_lds_bytes<64>(p) > 64 * 1024 || (p.D <= 32 && fast_lds_bytes<32>(p) > 64 * 1024)) return hipSuccess;   // absurd V (D <= 32: + the reference vectors)
     if (p.src_gmq && !(p.ablate & 0x100)) {                                                  // D > 32 with the quad-form (mu, sigma) map: the round-3 kernel (dev bit 0x100: the round-2 kernels)
 #ifdef MAGNET_DEV
-        // round 4's two measured experiments, dev builds only: 0x8 = quads AND texels staged in LDS by DMA, correlation on the
-        // matrix pipe (cost_volume_v4.hip: 1.24 - 1.35 ms, bound by LDS bytes per unit in flight); 0x20 = round 3's kernel with the quads
-        // prefetched one unit ahead by LDS-DMA (cost_volume_v5.hip: 1.11 ms: + 15 vector / + 30 scalar instructions per (pixel, view), 6 waves)
+        // round 4's two measured experiments, dev library only (profiles/r4/NOTES.md): 0x8 = quads AND texels staged in LDS by DMA, correlation on
+        // the matrix pipe (cost_volume_v4.hip: 1.24 - 1.35 ms); 0x20 = round 3's kernel with the quads prefetched one unit ahead (cost_volume_v5.hip: 1.11 ms)
         if (p.ablate & 0x8) {
             const hipError_t e4 = launch_cv_v4(p, stream, handled);
             if (e4 != hipSuccess || *handled) return e4;
@@ -385,26 +385,21 @@ hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled) 
         if (e != hipSuccess || *handled) return e;
     }
     if (!have_gmm) return hipSuccess;                                                         // (api.hip reports MAGNET_E_SHAPE)
-    if ((p.ablate & 0xff) == 0 || (p.ablate & 0x40)) {                                                 // (bit 15 with bit 14: fast64 dev variant)                                                 // D > 32: views batched per pixel (cost_volume_fast64.hip)
+    if (!(p.ablate & 0x800)) {                                                                // D > 32: views batched per pixel (cost_volume_fast64.hip); dev 0x800: the per-view kernel below
         const hipError_t e = launch_cv_fast64(p, stream, handled);
         if (e != hipSuccess || *handled) return e;
     }
     const int nchunk = (int)(p.F * esz / 16);
-    const bool no_mfma = (p.ablate & 1) == 0;                                                 // dev bit 8: correlation on the matrix pipe (measured slower)
     *handled = true;
     if (p.feat_bf16) {
-        if (nchunk == 8 && !no_mfma) return launch_fast_c<uint16_t, 2, true, 4, 1, 2>(p, stream);   // F = 64: matrix-pipe correlation at D > 32
-        if (nchunk == 8 && (p.ablate & 0x20)) return launch_fast_c<uint16_t, 1, true, 8, 0, 1>(p, stream);   // dev bit 13: 8 lanes x 16 B per unit
-        if (nchunk == 8)  return launch_fast_c<uint16_t, 2, true, 4, 0, 1>(p, stream);       // F = 64: 4 lanes x 32 B per (item, tap) unit
-        if (nchunk == 4 && !no_mfma) return launch_fast_c<uint16_t, 1, false, 8, 1, 1>(p, stream);  // F = 32
-        if (nchunk == 16 && !no_mfma) return launch_fast_c<uint16_t, 2, true, 8, 1, 4>(p, stream);  // F = 128
-        if (nchunk <= 8)  return launch_fast_c<uint16_t, 1, false, 8, 0, 1>(p, stream);
-        if (nchunk <= 16) return launch_fast_c<uint16_t, 2, false, 8, 0, 1>(p, stream);
+        if (nchunk == 8)  return launch_fast_c<uint16_t, 2, true, 4>(p, stream);             // F = 64: 4 lanes x 32 B per texel
+        if (nchunk <= 8)  return launch_fast_c<uint16_t, 1, false, 8>(p, stream);
+        if (nchunk <= 16) return launch_fast_c<uint16_t, 2, false, 8>(p, stream);
     } else {
-        if (nchunk == 16) return launch_fast_c<float, 2, true, 8, 0, 1>(p, stream);          // F = 64
-        if (nchunk <= 8)  return launch_fast_c<float, 1, false, 8, 0, 1>(p, stream);
-        if (nchunk <= 16) return launch_fast_c<float, 2, false, 8, 0, 1>(p, stream);
-        if (nchunk <= 32) return launch_fast_c<float, 4, false, 8, 0, 1>(p, stream);
+        if (nchunk == 16) return launch_fast_c<float, 2, true, 8>(p, stream);                // F = 64
+        if (nchunk <= 8)  return launch_fast_c<float, 1, false, 8>(p, stream);
+        if (nchunk <= 16) return launch_fast_c<float, 2, false, 8>(p, stream);
+        if (nchunk <= 32) return launch_fast_c<float, 4, false, 8>(p, stream);
     }
     *handled = false;                                                                         // very wide F: exact kernels
     return hipSuccess;

@@ -13,22 +13,37 @@
 // VG bilinear combines run: two memory round trips per GROUP instead of two per view.
 //
 // Arithmetic, tolerance contract, layouts: exactly cost_volume_fast.hip (see its header).
+//
+// Round 5: TEXEL-PAIR ITEMS (TX).  The candidates of a pixel walk along the view's epipolar segment, so the quads of consecutive
+// gate-open runs are neighbours and share two of their four texels (homography.py:150: grid_sample's 2 x 2 footprint): with quad
+// items 4 texels per run were fetched and correlated where ~2.2 distinct ones exist on the full-resolution grids (14 runs per
+// (pixel, view) at C2L).  Now an item is a PAIR of texels across the segment's direction of travel — a column {(y0, x), (y0+1, x)}
+// when the segment runs along x, a row {(y, x0), (y, x0+1)} when it runs along y.  The direction is the sign of the d-independent
+// numerator of d(P_x/P_z)/dd = (r_x t_z - t_x r_z) / P_z^2 (likewise y), evaluated once per (pixel, view) in the prologue.  A run's
+// quad is two consecutive pairs; a leader whose quad is the previous run's quad + one step along the direction of travel re-uses
+// that run's second pair and emits only one.  Slot numbering runs along increasing x (y), whatever the direction of travel, so the
+// combine is direction-free: c = lerp(lerp(pair s), lerp(pair s + 1)).  The mode only decides how many pairs are shared, never the
+// result: any (mode, direction) gives the same texels to the same quads.
 #include <stdlib.h>
 #include "cv_runs.hpp"
 
 namespace magnet {
 
 // CPL / FULL / LPU: as in cv_fast_kernel (VALU correlation units of LPU lanes x CPL 16-byte chunks)
-// VG = views per group (1..4); GBITS = write the gate bits (debug / parity tests)
-template <typename FeatT, int CPL, bool FULL, int MINW, int LPU, int VG, int GBITS_>
+// VG = views per group (1..4); OPT bit 0 = write the gate bits (debug / parity tests); bit 2 = texel-pair items (TX; the product form —
+// quad items are kept for dev A/B only)
+template <typename FeatT, int CPL, bool FULL, int MINW, int LPU, int VG, int OPT>
 __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) {
     constexpr int DL = 64;
-    constexpr bool GBITS = (GBITS_ & 1) != 0;
-    constexpr bool LEAD = (GBITS_ & 2) != 0;           // (mu,sigma) taps loaded once per run of equal quads, shared through LDS
-    constexpr int IPP = 64 / (4 * LPU);                   // items per correlation pass
-    constexpr int NPASS = 16 / IPP > 4 ? 4 : 16 / IPP;    // passes fetched together (<= 16 items, <= 4 passes)
+    constexpr bool GBITS = (OPT & 1) != 0;
+    constexpr bool TX = (OPT & 4) != 0;
+    constexpr int TPI = TX ? 2 : 4;                       // texels per item
+    constexpr int IPP = 64 / (TPI * LPU);                 // items per correlation pass
+    constexpr int NPASS = TX ? (32 / IPP > 4 ? 4 : 32 / IPP) : (16 / IPP > 4 ? 4 : 16 / IPP);   // passes fetched together (<= 4)
     constexpr int CSTR = LPU * 16;                        // byte stride between a lane's channel chunks
-    constexpr int CAP = 64;                               // item capacity of the LDS tables
+    constexpr int CAP = TX ? 128 : 64;                    // item capacity of the LDS tables (one view alone never needs more)
+    constexpr int CT_BYTES = TX ? (CAP + 2) * 8 : (CAP + 1) * 16;     // TX: [2 zero pairs | CAP pairs] x {c0, c1}; else [zero | CAP] x 4 taps
+    constexpr int IT_BYTES = TX ? (CAP + 2) * 8 : (CAP + 4) * 4;      // TX: {byte offset of texel 0, of texel 1}; else byte offset of the quad
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -51,13 +66,15 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
     const int OUT_PX = min(8, NPX);                       // pixels staged before a flush of row segments (NCHW fp32 output only)
     const int out_bytes = p.cost_hi ? 0 : OUT_PX * DL * 4;
     const int pv_bytes = p.V * NPX * 32;
-    const int wave_bytes = pv_bytes + (CAP + 1) * 16 + (CAP + 4) * 4 + out_bytes + (LEAD ? VG * 65 * 32 : 0);
+    const int md_bytes = TX ? (p.V * NPX * 4 + 15) / 16 * 16 : 0;
+    const int wave_bytes = pv_bytes + CT_BYTES + IT_BYTES + out_bytes + md_bytes;
     unsigned char* wbase = smem + wv * wave_bytes;
     float4*   pvtab = reinterpret_cast<float4*>(wbase);                                         // [V][NPX px][2]
-    float4*   ctab  = reinterpret_cast<float4*>(wbase + pv_bytes);                              // [zero slot | CAP items] x 4 taps
-    uint32_t* items = reinterpret_cast<uint32_t*>(wbase + pv_bytes + (CAP + 1) * 16);           // [CAP + pad] byte offsets
-    float*    outb  = reinterpret_cast<float*>(wbase + pv_bytes + (CAP + 1) * 16 + (CAP + 4) * 4);   // [OUT_PX][DL]
-    float4*   gslot = reinterpret_cast<float4*>(wbase + pv_bytes + (CAP + 1) * 16 + (CAP + 4) * 4 + out_bytes);   // LEAD: [VG][1 + 64 runs][2]
+    float4*   ctab  = reinterpret_cast<float4*>(wbase + pv_bytes);                              // quad items: [zero slot | CAP items] x 4 taps
+    float2*   ctab2 = reinterpret_cast<float2*>(wbase + pv_bytes);                              // pair items: [2 zero slots | CAP pairs] x 2 texels
+    uint32_t* items = reinterpret_cast<uint32_t*>(wbase + pv_bytes + CT_BYTES);                 // quad items: byte offsets; pair items: 2 per pair
+    float*    outb  = reinterpret_cast<float*>(wbase + pv_bytes + CT_BYTES + IT_BYTES);         // [OUT_PX][DL]
+    uint32_t* mtab  = reinterpret_cast<uint32_t*>(wbase + pv_bytes + CT_BYTES + IT_BYTES + out_bytes);   // TX: [V][NPX] bit 0 = travels along y, bit 1 = towards smaller coordinates
 
     // ---- depth-linear projection terms for the wave's 16 pixels x V views (once per tile row) ----
     for (int e = lane; e < NPX * p.V; e += 64) {
@@ -68,16 +85,18 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
         const PixelView pv = make_pixel_view(p.intM + (size_t)b * 9, p.poses + ((size_t)b * p.V + v) * 16, r0, r1, r2);
         pvtab[e * 2 + 0] = make_float4(pv.rpx, pv.rpy, pv.rpz, pv.rcz);
         pvtab[e * 2 + 1] = make_float4(pv.kt0, pv.kt1, pv.kt2, pv.tz);
+        if (TX) mtab[e] = travel_mode(pv);
     }
-    if (lane == 0) ctab[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (TX) { if (lane < 2) ctab2[lane] = make_float2(0.f, 0.f); }
+    else if (lane == 0) ctab[0] = make_float4(0.f, 0.f, 0.f, 0.f);
     fwave_lds_fence();
 
     const uint32_t texel_bytes = (uint32_t)p.F * (uint32_t)sizeof(FeatT);
     const int nchunk = (int)(texel_bytes / 16);
     const uint32_t xlim = __float_as_uint((float)(p.w + 1)), ylim = __float_as_uint((float)(p.h + 1));   // see cost_volume_fast.hip
     const int j0 = lane;
-    const int sub = lane & (LPU - 1), tap = (lane / LPU) & 3, upair = lane / (4 * LPU);          // correlation: chunk, tap, item of the pass
-    const uint32_t lane_src_off = (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes + (uint32_t)sub * 16u;
+    const int sub = lane & (LPU - 1), tap = (lane / LPU) & (TPI - 1), upair = lane / (TPI * LPU);   // correlation: chunk, texel of the item, item of the pass
+    const uint32_t lane_src_off = (TX ? 0u : (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes) + (uint32_t)sub * 16u;
     const unsigned char* __restrict__ ref_row = reinterpret_cast<const unsigned char*>(p.ref_feat) +
         ((size_t)b * hw + (size_t)yc * p.w) * texel_bytes;
     const float invV = 1.0f / (float)p.V;
@@ -99,6 +118,7 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
     const cvr_gptr src_b = (cvr_gptr)(unsigned long long)v4_uniform_ptr(reinterpret_cast<const unsigned char*>(p.src_feat) + (size_t)b * map_texels * texel_bytes);
     const cvr_gptr sgm_b = (cvr_gptr)(unsigned long long)v4_uniform_ptr(reinterpret_cast<const unsigned char*>(p.src_gmm) + (size_t)b * map_texels * 8);
     const float kappa = p.kappa;
+    const uint32_t row_bytes = (uint32_t)Wp * texel_bytes;
 
     for (int jb = 0; jb < JB; ++jb) {                                             // candidate block of 64 candidates
         const int j = jb * DL + j0;
@@ -123,13 +143,16 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
             d = live ? d : __builtin_nanf("");                                    // dead lane -> out of image below
             float acc = 0.f;
 
-            // (item, tap) dot products of items [0, n) of the LDS list -> ctab[1 + item]
+            // texel dot products of items [0, n) of the LDS list -> their slots (quad items: ctab[1 + item][tap]; pair items: ctab2[2 + item].{x, y})
             auto correlate = [&](const int n) {
                 for (int ps = 0; ps < n; ps += IPP * NPASS) {
                     uint4 sv[NPASS][CPL];
                     uint32_t off[NPASS];
 #pragma unroll
-                    for (int a = 0; a < NPASS; ++a) off[a] = items[min(ps + IPP * a + upair, n)];   // tail: the pad item
+                    for (int a = 0; a < NPASS; ++a) {                             // tail: the pad item
+                        const int it = min(ps + IPP * a + upair, n);
+                        off[a] = TX ? items[it * 2 + tap] : items[it];
+                    }
 #pragma unroll
                     for (int a = 0; a < NPASS; ++a) {
                         if (a > 0 && ps + IPP * a >= n) break;                    // wave-uniform: this pass holds no item
@@ -146,17 +169,21 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
                         for (int cc = 0; cc < CPL; ++cc) part = fdot_chunk(rvp[cc], sv[a][cc], part, FeatT());
                         part = LPU == 8 ? freduce8(part) : freduce4(part);
                         const int it = ps + IPP * a + upair;
-                        if (sub == 0 && it < n) reinterpret_cast<float*>(ctab + it + 1)[tap] = part;
+                        if (sub == 0 && it < n) {
+                            if (TX) reinterpret_cast<float*>(ctab2 + it + 2)[tap] = part;
+                            else reinterpret_cast<float*>(ctab + it + 1)[tap] = part;
+                        }
                     }
                 }
             };
 
             for (int v0 = 0; v0 < p.V; v0 += VG) {
                 // ---------------- phase A: geometry, (mu,sigma) taps, gate, distinct open quads — VG independent chains ----------------
-                float wnw[VG], wne[VG], wsw[VG], wse[VG];
+                float wa[VG], wb[VG], wc[VG], wd[VG];                              // quad items: the four bilinear weights; pair items: {bx, by}
                 uint32_t qoff[VG];                                                // byte offset of the quad's first texel in the frame's views
-                int incl[VG], cnt[VG];
-                bool gate[VG], fresh[VG];
+                int incl[VG], cnt[VG];                                            // quad items: items at or below the lane / of the view; pair items: first slot (travel order) / pairs of the view
+                bool gate[VG], fresh[VG], shr[VG];
+                uint32_t md[VG];
                 float zw[VG];
                 uint32_t qi[VG];
                 bool inwin[VG];
@@ -170,6 +197,7 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
                     for (int u = 0; u < VG; ++u) {
                         const int vv = min(v0 + u, p.V - 1);                      // tail group: clamped view, masked below
                         pa[u] = pvtab[(vv * NPX + q) * 2 + 0]; pb[u] = pvtab[(vv * NPX + q) * 2 + 1];
+                        if (TX) md[u] = __builtin_amdgcn_readfirstlane(mtab[vv * NPX + q]);
                     }
 #pragma unroll
                     for (int u = 0; u < VG; ++u) {
@@ -184,40 +212,20 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
                         const float x0f = __builtin_floorf(ixs), y0f = __builtin_floorf(iys);
                         const float bx = ixs - x0f, by = iys - y0f;
                         const float ax = 1.0f - bx, ay = 1.0f - by;
-                        wnw[u] = ax * ay; wne[u] = bx * ay; wsw[u] = ax * by; wse[u] = bx * by;   // homography.py:150-152
+                        wa[u] = ax * ay; wb[u] = bx * ay; wc[u] = ax * by; wd[u] = bx * by;   // homography.py:150-152
                         inwin[u] = (__float_as_uint(ixs) < xlim) && (__float_as_uint(iys) < ylim);
                         // clamp in float first (v_med3_f32; NaN -> 0): the float -> unsigned conversion is then defined
                         const uint32_t xq = (uint32_t)__builtin_amdgcn_fmed3f(x0f, 0.0f, (float)p.w);
                         const uint32_t yq = (uint32_t)__builtin_amdgcn_fmed3f(y0f, 0.0f, (float)p.h);
                         qi[u] = __umul24(yq, (uint32_t)Wp) + xq;                 // quad origin in the padded map (exact when inwin)
                         const cvr_gptr sgm = (cvr_gptr)(unsigned long long)v4_uniform_ptr((const void*)(sgm_b + (size_t)vv * sgm_vstride));
-                        if (!LEAD) {
-                            g0[u] = v3_gld_f4(sgm + qi[u] * 8u);             // (mu,sg) x0, x0+1 of row y0
-                            g1[u] = v3_gld_f4(sgm + (qi[u] + (uint32_t)Wp) * 8u);
+                        g0[u] = v3_gld_f4(sgm + qi[u] * 8u);                     // (mu,sg) x0, x0+1 of row y0
+                        g1[u] = v3_gld_f4(sgm + (qi[u] + (uint32_t)Wp) * 8u);
+                        if (TX) {                                                 // the gate below needs the four weights, the combine only the fractions
+                            const float mu_w = __builtin_fmaf(g1[u].z, wd[u], __builtin_fmaf(g1[u].x, wc[u], __builtin_fmaf(g0[u].z, wb[u], g0[u].x * wa[u])));
+                            const float sg_w = __builtin_fmaf(g1[u].w, wd[u], __builtin_fmaf(g1[u].y, wc[u], __builtin_fmaf(g0[u].w, wb[u], g0[u].y * wa[u])));
+                            wc[u] = mu_w; wd[u] = sg_w; wa[u] = bx; wb[u] = by;
                         }
-                    }
-                    if (LEAD) {
-                        // candidates are sorted along the epipolar segment: lanes on the same quad form runs; the first lane of a
-                        // run loads the 2 x 16 bytes (64 -> ~7 L1 accesses per load), the run shares them through an LDS slot
-                        int run[VG];
-#pragma unroll
-                        for (int u = 0; u < VG; ++u) {
-                            const int vv = min(v0 + u, p.V - 1);
-                            const cvr_gptr sgm = (cvr_gptr)(unsigned long long)v4_uniform_ptr((const void*)(sgm_b + (size_t)vv * sgm_vstride));
-                            const uint32_t tkey = inwin[u] ? qi[u] : FKEY_CLOSED;
-                            const uint32_t tprev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)tkey, 0x138, 0xf, 0xf, false);
-                            const bool lead = inwin[u] && (tkey != tprev);
-                            const unsigned long long lbal = __builtin_amdgcn_ballot_w64(lead);
-                            run[u] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lbal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lbal, lead ? 1u : 0u));
-                            if (lead) {
-                                gslot[(u * 65 + run[u]) * 2 + 0] = v3_gld_f4(sgm + qi[u] * 8u);
-                                gslot[(u * 65 + run[u]) * 2 + 1] = v3_gld_f4(sgm + (qi[u] + (uint32_t)Wp) * 8u);
-                            }
-                        }
-                        fwave_lds_fence();
-#pragma unroll
-                        for (int u = 0; u < VG; ++u) { g0[u] = gslot[(u * 65 + run[u]) * 2 + 0]; g1[u] = gslot[(u * 65 + run[u]) * 2 + 1]; }
-                        fwave_lds_fence();
                     }
                 }
 #pragma unroll
@@ -225,10 +233,14 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
                     // A3: consistency gate, distinct open quads
                     const int vv = min(v0 + u, p.V - 1);
                     const bool vok = (v0 + u < p.V) && ((vmask >> vv) & 1ull);    // homography.py:97 (wave-uniform)
-                    float mu_w = g0[u].x * wnw[u], sg_w = g0[u].y * wnw[u];
-                    mu_w = __builtin_fmaf(g0[u].z, wne[u], mu_w); sg_w = __builtin_fmaf(g0[u].w, wne[u], sg_w);
-                    mu_w = __builtin_fmaf(g1[u].x, wsw[u], mu_w); sg_w = __builtin_fmaf(g1[u].y, wsw[u], sg_w);
-                    mu_w = __builtin_fmaf(g1[u].z, wse[u], mu_w); sg_w = __builtin_fmaf(g1[u].w, wse[u], sg_w);
+                    float mu_w, sg_w;
+                    if (TX) { mu_w = wc[u]; sg_w = wd[u]; }
+                    else {
+                        mu_w = g0[u].x * wa[u]; sg_w = g0[u].y * wa[u];
+                        mu_w = __builtin_fmaf(g0[u].z, wb[u], mu_w); sg_w = __builtin_fmaf(g0[u].w, wb[u], sg_w);
+                        mu_w = __builtin_fmaf(g1[u].x, wc[u], mu_w); sg_w = __builtin_fmaf(g1[u].y, wc[u], sg_w);
+                        mu_w = __builtin_fmaf(g1[u].z, wd[u], mu_w); sg_w = __builtin_fmaf(g1[u].w, wd[u], sg_w);
+                    }
                     gate[u] = vok & inwin[u] & (__builtin_fabsf(zw[u] - mu_w) < sg_w * kappa);     // homography.py:157-158
                     if (GBITS && live && vok)
                         p.gate_bits[(((size_t)b * p.V + vv) * p.D + j) * hw + (size_t)y * p.w + x] = gate[u] ? 1 : 0;
@@ -237,15 +249,74 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
                     const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)FKEY_CLOSED, (int)key, 0x138, 0xf, 0xf, false);  // wave_shr:1
                     fresh[u] = gate[u] && (key != prev);
                     const unsigned long long bal = __builtin_amdgcn_ballot_w64(fresh[u]);
-                    cnt[u] = __popcll(bal);
-                    incl[u] = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                   __builtin_amdgcn_mbcnt_lo((uint32_t)bal, fresh[u] ? 1u : 0u));  // view's items at or below this lane
+                    const int nl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((uint32_t)bal, fresh[u] ? 1u : 0u));   // leaders at or below this lane
+                    if (TX) {
+                        // a leader whose quad is the previous run's quad moved one step along the direction of travel shares that run's
+                        // second pair (FKEY_CLOSED +- a step is no valid key)
+                        const uint32_t step = ((md[u] & 1u) ? (uint32_t)Wp : 1u) * ((md[u] & 2u) ? 0xffffffffu : 1u);
+                        shr[u] = fresh[u] && (prev + step == key);
+                        const unsigned long long sbal = __builtin_amdgcn_ballot_w64(shr[u]);
+                        const int ns = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sbal >> 32),
+                                            __builtin_amdgcn_mbcnt_lo((uint32_t)sbal, shr[u] ? 1u : 0u));
+                        cnt[u] = 2 * v4_popc(bal) - v4_popc(sbal);               // pairs of this view
+                        incl[u] = 2 * (nl - 1) - ns;                              // the lane's first pair, numbered in travel order
+                    } else {
+                        cnt[u] = __popcll(bal);
+                        incl[u] = nl;
+                    }
                 }
                 int n_tot = 0;
 #pragma unroll
                 for (int u = 0; u < VG; ++u) n_tot += cnt[u];
                 if (n_tot == 0) continue;                                         // wave-uniform: nothing open in this group
-                if (n_tot <= CAP) {
+                if (TX) {
+                    // ---------------- pair items: phase B (lists), correlation, phase C (combine) — the whole group, or view by view if the tables overflow ----------------
+                    const bool whole = n_tot <= CAP;
+                    int base = 2;                                                 // slots 0, 1: the zero pairs of closed lanes
+#pragma unroll
+                    for (int u = 0; u < VG; ++u) {
+                        if (!whole) base = 2;
+                        const bool neg = (md[u] & 2u) != 0, rowm = (md[u] & 1u) != 0;
+                        // slots are numbered along increasing x (y): travelling towards smaller coordinates reverses the view's numbering
+                        const int s = neg ? base + cnt[u] - 2 - incl[u] : base + incl[u];
+                        const uint32_t oJ = rowm ? row_bytes : texel_bytes, oM = rowm ? texel_bytes : row_bytes;
+                        // the pair a sharing leader re-uses: its first (in coordinate order) when travelling up, its second when travelling down
+                        if (fresh[u] && !(shr[u] && !neg)) *reinterpret_cast<uint2*>(items + (s - 2) * 2) = make_uint2(qoff[u], qoff[u] + oM);
+                        if (fresh[u] && !(shr[u] && neg))  *reinterpret_cast<uint2*>(items + (s - 1) * 2) = make_uint2(qoff[u] + oJ, qoff[u] + oJ + oM);
+                        incl[u] = gate[u] ? s : 0;
+                        base += cnt[u];
+                        if (!whole) {
+                            if (cnt[u] == 0) continue;                            // wave-uniform
+                            if (lane == 0) *reinterpret_cast<uint2*>(items + cnt[u] * 2) = make_uint2(0u, 0u);
+                            fwave_lds_fence();
+                            correlate(cnt[u]);
+                            fwave_lds_fence();
+                            const float2 cA = ctab2[incl[u]], cB = ctab2[incl[u] + 1];
+                            const float fmin = rowm ? wa[u] : wb[u], fmaj = rowm ? wb[u] : wa[u];
+                            const float t = __builtin_fmaf(fmin, cA.y - cA.x, cA.x), l = __builtin_fmaf(fmin, cB.y - cB.x, cB.x);
+                            const float c = __builtin_fmaf(fmaj, l - t, t);       // homography.py:150,155 (grid_sample's bilinear weights, factored)
+                            acc += gate[u] ? c : 0.f;
+                            fwave_lds_fence();
+                        }
+                    }
+                    if (whole) {
+                        if (lane == 0) *reinterpret_cast<uint2*>(items + n_tot * 2) = make_uint2(0u, 0u);   // pad item: view 0, texel 0
+                        fwave_lds_fence();
+                        correlate(n_tot);
+                        fwave_lds_fence();
+#pragma unroll
+                        for (int u = 0; u < VG; ++u) {
+                            const bool rowm = (md[u] & 1u) != 0;
+                            const float2 cA = ctab2[incl[u]], cB = ctab2[incl[u] + 1];
+                            const float fmin = rowm ? wa[u] : wb[u], fmaj = rowm ? wb[u] : wa[u];
+                            const float t = __builtin_fmaf(fmin, cA.y - cA.x, cA.x), l = __builtin_fmaf(fmin, cB.y - cB.x, cB.x);
+                            const float c = __builtin_fmaf(fmaj, l - t, t);       // homography.py:150,155
+                            acc += gate[u] ? c : 0.f;                             // homography.py:159,116 (fp32 here)
+                        }
+                        fwave_lds_fence();                                        // the tables are rewritten by the next group
+                    }
+                } else if (n_tot <= CAP) {
                     // ---------------- phase B: one item list for the group ----------------
                     int base = 0;
 #pragma unroll
@@ -262,10 +333,10 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
 #pragma unroll
                     for (int u = 0; u < VG; ++u) {
                         const float4 c4 = ctab[incl[u]];
-                        float c = c4.x * wnw[u];
-                        c = __builtin_fmaf(c4.y, wne[u], c);
-                        c = __builtin_fmaf(c4.z, wsw[u], c);
-                        c = __builtin_fmaf(c4.w, wse[u], c);
+                        float c = c4.x * wa[u];
+                        c = __builtin_fmaf(c4.y, wb[u], c);
+                        c = __builtin_fmaf(c4.z, wc[u], c);
+                        c = __builtin_fmaf(c4.w, wd[u], c);
                         acc += gate[u] ? c : 0.f;                                 // homography.py:159,116 (fp32 here)
                     }
                     fwave_lds_fence();                                            // ctab/items are rewritten by the next group
@@ -280,10 +351,10 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
                         correlate(cnt[u]);
                         fwave_lds_fence();
                         const float4 c4 = ctab[gate[u] ? incl[u] : 0];
-                        float c = c4.x * wnw[u];
-                        c = __builtin_fmaf(c4.y, wne[u], c);
-                        c = __builtin_fmaf(c4.z, wsw[u], c);
-                        c = __builtin_fmaf(c4.w, wse[u], c);
+                        float c = c4.x * wa[u];
+                        c = __builtin_fmaf(c4.y, wb[u], c);
+                        c = __builtin_fmaf(c4.z, wc[u], c);
+                        c = __builtin_fmaf(c4.w, wd[u], c);
                         acc += gate[u] ? c : 0.f;
                         fwave_lds_fence();
                     }
@@ -319,8 +390,9 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
     }
 }
 
-static size_t fast64_lds_bytes(const CvParams& p, int lead_vg = 0) {
-    return (size_t)4 * (p.V * p.npx * 32 + 65 * 16 + 68 * 4 + (p.cost_hi ? 0 : (p.npx < 8 ? p.npx : 8) * 64 * 4) + lead_vg * 65 * 32);
+static size_t fast64_lds_bytes(const CvParams& p, bool tx) {
+    const size_t tables = tx ? (size_t)(130 * 8 + 130 * 8 + (p.V * p.npx * 4 + 15) / 16 * 16) : (size_t)(65 * 16 + 68 * 4);
+    return (size_t)4 * (p.V * p.npx * 32 + tables + (p.cost_hi ? 0 : (p.npx < 8 ? p.npx : 8) * 64 * 4));
 }
 
 template <typename FeatT, int CPL, bool FULL, int MINW, int LPU, int VG>
@@ -333,18 +405,18 @@ static hipError_t launch_fast64_v(const CvParams& p0, hipStream_t stream) {
     // prologue (projection table, validity mask) than it saves.
     CvParams p = p0;
     p.npx = 8;
-    if (p.ablate & 0x40) p.npx = 1 << ((p.ablate >> 3) & 7) > 16 ? 16 : 1 << ((p.ablate >> 3) & 7);   // dev: path bits 11..13 = log2(NPX)
     p.tiles_x = (p.w + 4 * p.npx - 1) / (4 * p.npx);
     p.tiles_y = p.h;
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
-    if constexpr (sizeof(FeatT) == 2 && FULL) {
-        if (p.ablate & 0x80) {                                                    // dev (path bit 15): leader (mu,sigma) loads through LDS
-            hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 2>), grid, block, fast64_lds_bytes(p, VG), stream, p);
-            return hipGetLastError();
-        }
+#ifdef MAGNET_DEV
+    if (p.ablate & 0x400) {                                                       // dev: quad items (rounds 2 - 4) for same-box A/B
+        if (p.gate_bits) hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 1>), grid, block, fast64_lds_bytes(p, false), stream, p);
+        else hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 0>), grid, block, fast64_lds_bytes(p, false), stream, p);
+        return hipGetLastError();
     }
-    if (p.gate_bits) hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 1>), grid, block, fast64_lds_bytes(p), stream, p);
-    else hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 0>), grid, block, fast64_lds_bytes(p), stream, p);
+#endif
+    if (p.gate_bits) hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 5>), grid, block, fast64_lds_bytes(p, true), stream, p);
+    else hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 4>), grid, block, fast64_lds_bytes(p, true), stream, p);
     return hipGetLastError();
 }
 
@@ -353,7 +425,6 @@ static hipError_t launch_fast64(const CvParams& p, hipStream_t stream) {
     // views per group: as many as possible (<= 4) without idle slots in the last group
     int vg = p.V >= 4 ? 4 : p.V;
     if (p.V > 4 && p.V % 4 != 0 && (p.V % 3 == 0 || p.V % 4 < p.V % 3)) vg = 3;
-    if (p.ablate & 0x40) vg = 1 + ((p.ablate >> 1) & 3);                          // dev: path bits 9..10 choose VG - 1 when bit 14 is set
     switch (vg) {
         case 1: return launch_fast64_v<FeatT, CPL, FULL, MINW, LPU, 1>(p, stream);
         case 2: return launch_fast64_v<FeatT, CPL, FULL, MINW, LPU, 2>(p, stream);
@@ -372,17 +443,7 @@ hipError_t launch_cv_fast64(const CvParams& p, hipStream_t stream, bool* handled
     const int nchunk = (int)(p.F * esz / 16);
     *handled = true;
     if (p.feat_bf16) {
-        if (nchunk == 8) {                                                                 // F = 64: 4 lanes x 32 B per (item, tap) unit
-#ifdef MAGNET_DEV
-            static const int dev_minw = getenv("MAGNET_MATCH_MINW") ? atoi(getenv("MAGNET_MATCH_MINW")) : 0;   // dev: occupancy A/B
-#else
-            constexpr int dev_minw = 0;
-#endif
-            if (dev_minw == 4) return launch_fast64<uint16_t, 2, true, 4, 4>(p, stream);
-            if (dev_minw == 6) return launch_fast64<uint16_t, 2, true, 6, 4>(p, stream);
-            if (dev_minw == 8) return launch_fast64<uint16_t, 2, true, 8, 4>(p, stream);
-            return launch_fast64<uint16_t, 2, true, 5, 4>(p, stream);
-        }
+        if (nchunk == 8)  return launch_fast64<uint16_t, 2, true, 5, 4>(p, stream);       // F = 64: 4 lanes x 32 B per texel
         if (nchunk <= 8)  return launch_fast64<uint16_t, 1, false, 5, 8>(p, stream);
         if (nchunk <= 16) return launch_fast64<uint16_t, 2, false, 5, 8>(p, stream);
     } else {

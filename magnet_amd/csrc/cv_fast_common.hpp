@@ -42,6 +42,18 @@ __device__ __forceinline__ void fwave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr uint32_t FKEY_CLOSED = 0xffffffffu;
+// key of a lane without an open quad.  Valid keys are below 2^24 (launchers check), and FKEY_CLOSED +- a step of the padded map is
+// none either, so "previous lane's key + step == my key" needs no separate test for a closed previous lane.
+constexpr uint32_t FKEY_CLOSED = 0x40000000u;
+
+// Direction in which the candidates of one (pixel, view) travel through the source map as the depth grows (round 5, texel-pair
+// items).  P(d) = t + r d (homography.py:132), so d(P_x / P_z)/dd = (r_x t_z - t_x r_z) / P_z^2: the sign and the dominant axis do
+// not depend on d.  bit 0: the segment runs along y (pairs are rows); bit 1: towards smaller coordinates.  Speed only — the mode
+// decides how many texel pairs consecutive quads share, never the result.
+__device__ __forceinline__ uint32_t travel_mode(const PixelView& pv) {
+    const float nx = pv.rpx * pv.kt2 - pv.kt0 * pv.rpz, ny = pv.rpy * pv.kt2 - pv.kt1 * pv.rpz;
+    const bool rowm = __builtin_fabsf(ny) > __builtin_fabsf(nx);
+    return (rowm ? 1u : 0u) | (((rowm ? ny : nx) < 0.f) ? 2u : 0u);
+}
 
 }  // namespace magnet

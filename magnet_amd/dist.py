@@ -20,14 +20,24 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
-def init_from_env(backend: str | None = None):
-    """Initialise torch.distributed from the torchrun environment.  A plain `python bench.py` (no RANK in the
-    environment) stays single-process; under torchrun the group is created even for one rank, so the N = 1 launch
-    exercises the same rendezvous / RCCL path as N = 8."""
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def init_from_env(backend: str | None = None, always: bool = False):
+    """Initialise torch.distributed from the torchrun environment.  Under torchrun the group is created even for one rank;
+    `always=True` (bench.py on a GPU) also creates a ONE-rank group for a plain `python bench.py` (no RANK in the environment,
+    rendezvous on a free local port), so that the N = 1 launch exercises the same rendezvous / RCCL path as N = 8
+    (train_MaGNet.py:197-210 is the reference's pattern).  Without `always` a plain launch stays single-process."""
     rank, world, local = env_world()
-    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
+    if (world > 1 or "RANK" in os.environ or always) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_PORT", "29533" if "RANK" in os.environ else str(_free_port()))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -73,8 +83,10 @@ def shard_range(n_items: int, rank: int, world: int):
 
 @torch.no_grad()
 def broadcast_module_(module: torch.nn.Module, src: int = 0):
-    """Broadcast all parameters and buffers of `module` from rank `src`, one flat bucket per dtype."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    """Broadcast all parameters and buffers of `module` from rank `src`, one flat bucket per dtype.  Runs whenever a process group
+    exists — also a one-rank group, so that the N = 1 launch drives the same collective (and reports the same byte count) as N = 8.
+    Returns the bytes broadcast (0 without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()):
         return 0
     by_dtype: dict = {}
     for t in list(module.parameters()) + list(module.buffers()):
@@ -90,6 +102,25 @@ def broadcast_module_(module: torch.nn.Module, src: int = 0):
             off += n
         nbytes += flat.numel() * flat.element_size()
     return nbytes
+
+
+@torch.no_grad()
+def module_checksum(module: torch.nn.Module) -> float:
+    """Order-dependent float64 checksum of all parameters and buffers (sum of element x (1 + index mod 251))."""
+    acc = 0.0
+    for t in list(module.parameters()) + list(module.buffers()):
+        if not t.is_floating_point():
+            t = t.double()
+        f = t.detach().reshape(-1).double()
+        w = (torch.arange(f.numel(), device=f.device, dtype=torch.float64) % 251) + 1.0
+        acc += float((f * w).sum().item())
+    return acc
+
+
+def broadcast_verified(module: torch.nn.Module, device=None) -> bool:
+    """After broadcast_module_: every rank holds bit-identical weights <=> the checksums gathered from all ranks are equal."""
+    vals = gather_floats(module_checksum(module), device=device)
+    return all(v == vals[0] for v in vals)
 
 
 def max_over_ranks(value: float, device=None) -> float:
@@ -109,8 +140,8 @@ def sum_over_ranks(value: float, device=None) -> float:
 
 
 def gather_floats(value: float, device=None) -> list:
-    """[value of rank 0, ..., value of rank world-1] on every rank (one tiny all_gather)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    """[value of rank 0, ..., value of rank world-1] on every rank (one tiny all_gather; also in a one-rank group)."""
+    if not (dist.is_available() and dist.is_initialized()):
         return [float(value)]
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]

@@ -533,6 +533,12 @@ def pack_mx(x_nchw, out_f16, out_qr, out_sc, ctot, c_off, sc_rows):
         raise MagnetError(f"pack_mx: unsupported input strides {x_nchw.stride()}")
     if out_f16.dtype != torch.float16 or out_qr.element_size() != 2 or out_sc.dtype != torch.int32:
         raise MagnetError("pack_mx: out_f16 fp16, out_qr a 2-byte dtype, out_sc int32")
+    rows = N * (h + 2) * (w + 2)
+    for name, t, need in (("out_f16", out_f16, rows * int(ctot)), ("out_qr", out_qr, rows * int(ctot)), ("out_sc", out_sc, (int(ctot) // 32) * int(sc_rows))):
+        if not t.is_cuda or t.device != x_nchw.device or not t.is_contiguous() or t.numel() < need:
+            raise MagnetError(f"pack_mx: {name} must be a contiguous tensor on {x_nchw.device} with at least {need} elements")
+    if int(ctot) % 32 or int(c_off) % 32 or int(c_off) + C > int(ctot) or int(sc_rows) < rows:
+        raise MagnetError("pack_mx: ctot / c_off must be multiples of 32 with c_off + C <= ctot, and sc_rows >= N (h+2) (w+2)")
     with torch.cuda.device(x_nchw.device):
         _check(lib.magnet_pack_mx(x_nchw.data_ptr(), out_f16.data_ptr(), out_qr.data_ptr(), out_sc.data_ptr(), N, C, h, w, int(ctot),
                                   int(c_off), int(sc_rows), int(x_nchw.stride(0)) if N > 1 else 0, _stream(x_nchw)), "magnet_pack_mx")

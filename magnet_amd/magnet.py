@@ -97,8 +97,7 @@ class MAGNET(nn.Module):
     `args` carries the same fields (MAGNET_sampling_range, MAGNET_num_samples, MAGNET_mvs_weighting,
     MAGNET_num_train_iter, MAGNET_num_test_iter, dpv_height, dpv_width, downsample_ratio).  The frozen
     backbones are out of this build's scope: pass them as `d_net` (img -> ((N,2,h,w), (N,256,h,w))) and
-    `f_net` (img -> (N,F,h,w)); if omitted, the reference's own `models.DNET.DNET` / `models.FNET.FNET`
-    are imported when the caller has them on sys.path (they need torch.hub / checkpoints).
+    `f_net` (img -> (N,F,h,w)); both are required (an omitted backbone is an error naming the argument).
     `feat_dtype`: 'fp32' or 'bf16' storage of F-Net features inside the matcher.
     `conv_backend`: 'mfma' runs g_net / mask_head on the bf16x3 matrix-core kernel at inference (csrc/conv_mfma.hip,
     fp32-grade); 'torch' keeps them on nn.Conv2d (MIOpen).  Autograd always takes the torch path."""
@@ -108,21 +107,11 @@ class MAGNET(nn.Module):
         super().__init__()
         self.args = args
         if d_net is None or f_net is None:
-            try:
-                from models.DNET import DNET      # the user's MaGNet checkout
-                from models.FNET import FNET
-            except Exception as e:  # pragma: no cover
-                raise lib.MagnetError(
-                    "MAGNET needs the frozen D-Net and F-Net: pass d_net=/f_net= modules, or put the "
-                    "MaGNet repository on sys.path so models.DNET / models.FNET import") from e
-            if d_net is None:
-                d_net = DNET(args, dnet=False)
-                if getattr(args, "DNET_ckpt", None):
-                    d_net = load_checkpoint(args.DNET_ckpt, d_net)
-            if f_net is None:
-                f_net = FNET(args)
-                if getattr(args, "FNET_ckpt", None):
-                    f_net = load_checkpoint(args.FNET_ckpt, f_net)
+            # The reference builds its frozen backbones itself (MAGNET.py:97-108: DNET needs torch.hub + a checkpoint).  This module
+            # accelerates the matching path only: the caller constructs them (the reference's own classes, or magnet_amd.fnet.FNET for
+            # the F-Net) and hands them over — there is no import fallback to a MaGNet checkout.
+            raise lib.MagnetError("MAGNET(args, d_net=..., f_net=...): both backbone modules are required "
+                                  "(d_net: img -> ((N,2,h,w), (N,256,h,w)); f_net: img -> (N,F,h,w)); see INTEGRATION.md")
         self.d_net = d_net
         self.f_net = f_net
         for net in (self.d_net, self.f_net):

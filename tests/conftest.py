@@ -42,8 +42,13 @@ def golden_r3():
 
 @pytest.fixture(scope="session")
 def hip_lib():
-    """Build (if stale) and load libmagnet_hip.so."""
+    """Build (if stale) and load libmagnet_hip.so.  MAGNET_TEST_DEV_LIB=1 (development only) runs the suite against the -DMAGNET_DEV
+    library instead, so that MAGNET_DEV_FLAGS can route every case through a kernel variant (tools/README.md)."""
     from magnet_amd import build, lib
+    if os.environ.get("MAGNET_TEST_DEV_LIB") == "1":
+        build.build(dev=True)
+        lib.use_dev_build()
+        return lib.load()
     build.build()
     return lib.load()
 

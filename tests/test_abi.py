@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     for s in _declared_symbols():
         assert hasattr(hip_lib, s), f"{s} declared in include/magnet_hip.h but not exported"
     assert set(_declared_symbols()) == set(lib.API_SYMBOLS)
-    assert hip_lib.magnet_version() == 302
+    assert hip_lib.magnet_version() == 400
 
 
 @pytest.mark.parametrize("struct", ["MagnetCostVolumeArgs", "MagnetConvArgs"])

@@ -90,8 +90,8 @@ CASES = [
     ("C4", "C4", 1, 0, "fp32", ()),
     ("C5", "C5", 1, 2, "fp32", ()),
     ("shipped-D5", "shipped", 2, 0, "fp32", ()),
-    # bf16 F = 64 at D > 32: the round-4 asynchronous kernel (cost_volume_v4.hip).  C4 (D = 128: two candidate blocks, long KITTI
-    # segments -> views with more than 32 distinct quads take the multi-round path) and C5 (V = 6, an invalid view)
+    # bf16 F = 64 at D > 32 (cost_volume_v3.hip's production instance): C4 (D = 128: two candidate blocks, long KITTI segments) and
+    # C5 (V = 6, an invalid view: the compacted view table)
     ("C4-bf16", "C4", 1, 0, "bf16", ()),
     ("C5-bf16-invalid", "C5", 2, 2, "bf16", ((0, 3), (1, 0))),
 ]

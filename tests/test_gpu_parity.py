@@ -453,6 +453,58 @@ def test_full_step_bench_size_batch_invariance(hip_lib, gpu):
         assert torch.isfinite(one).all() and torch.equal(one[0], full[b]), f"frame {b}"
 
 
+def test_full_step_bench_size_I3_hoisted_invariant(hip_lib, gpu):
+    """BASELINE config 3 at the bench.py batch: 64 frames, I = 3 — the refinement loop with the loop-invariant x_d3 convolution hoisted
+    out of the iterations (magnet.py: _refine_mfma).  (a) Frame by frame the three outputs equal a single-frame run bit for bit (no
+    cross-frame state in the hoisted partial sums, the per-iteration launches or the matcher); (b) frame 63 against the ORACLE loop on
+    the CPU (oracle matcher, torch-CPU G-Net / mask head, oracle update and upsampling; models/MAGNET.py:150-173): abs_rel < 1e-4
+    (north_star) for every iteration."""
+    from magnet_amd.magnet import MAGNET
+    wl = synth.WORKLOADS["C3"]
+    B, I = 64, 3
+    args = make_args(D=wl.D, iters=I, dpv_h=wl.h, dpv_w=wl.w, V=wl.V)
+    model = MAGNET(args, d_net=StubDNet(0), f_net=StubFNet(1), feat_dtype="bf16").eval()
+    seeded_magnet_weights(model, seed=8)
+    cpu_inp = synth.make_inputs(wl, B=B, seed=654, round_bf16=True)
+    x_d3_cpu = torch.randn(B, 256, wl.h, wl.w, generator=torch.Generator().manual_seed(5)) * 0.5
+    V, b = wl.V, B - 1
+    k = oracle.depth_sampling(3, wl.D)
+    with torch.no_grad():                                              # the oracle loop for frame 63 (CPU)
+        idx = [v * B + b for v in range(V)]
+        case = dict(ref_feat=cpu_inp["ref_feat"][b:b + 1], nghbr_feat=cpu_inp["nghbr_feat"][idx], nghbr_gmms=cpu_inp["nghbr_gmms"][idx],
+                    nghbr_poses=cpu_inp["nghbr_poses"][b:b + 1], is_valid=cpu_inp["is_valid"][b:b + 1],
+                    cam_intrins={kk: vv[b:b + 1] for kk, vv in cpu_inp["cam_intrins"].items()})
+        gmm, x3 = cpu_inp["ref_gmms"][b:b + 1].clone(), x_d3_cpu[b:b + 1]
+        mask = model.mask_head(x3)
+        want = []
+        for _ in range(I):
+            cost = torch.from_numpy(oracle_cost(dict(case, ref_gmms=gmm), k))
+            raw = model.g_net.gnet(torch.cat([cost, x3], dim=1))
+            gmm = torch.from_numpy(oracle.gaussian_update(raw.numpy(), gmm.numpy()))
+            want.append(oracle.upsample_depth_via_mask(gmm.numpy(), mask.numpy(), 4))
+    model = model.to(gpu)
+    inp = to_dev(cpu_inp, gpu)
+    x_d3 = x_d3_cpu.to(gpu)
+    with torch.no_grad():
+        full = [o.clone() for o in model.match_and_refine(inp["ref_gmms"], x_d3, inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"],
+                                                          inp["nghbr_poses"], inp["is_valid"], inp["cam_intrins"], mode="test")]
+    assert len(full) == I
+    for f in (0, b):
+        sel = lambda t: t[f:f + 1].contiguous()
+        nb = inp["nghbr_feat"].view(V, B, *inp["nghbr_feat"].shape[1:])[:, f:f + 1].reshape(V, *inp["nghbr_feat"].shape[1:]).contiguous()
+        ng = inp["nghbr_gmms"].view(V, B, *inp["nghbr_gmms"].shape[1:])[:, f:f + 1].reshape(V, *inp["nghbr_gmms"].shape[1:]).contiguous()
+        with torch.no_grad():
+            one = model.match_and_refine(sel(inp["ref_gmms"]), sel(x_d3), sel(inp["ref_feat"]), nb, ng, sel(inp["nghbr_poses"]),
+                                         sel(inp["is_valid"]), {kk: sel(v) for kk, v in inp["cam_intrins"].items()}, mode="test")
+        for i in range(I):
+            assert torch.isfinite(one[i]).all() and torch.equal(one[i][0], full[i][f]), f"frame {f}, iteration {i}"
+    for i in range(I):
+        got = full[i][b:b + 1].cpu().numpy()
+        abs_rel = oracle.abs_rel(np.abs(want[i][:, 0]) + 1e-3, np.abs(got[:, 0]) + 1e-3)
+        print(f"[C3 bench size, frame {b}, iteration {i}] abs_rel(production HIP loop vs oracle loop) = {abs_rel:.3e}")
+        assert abs_rel < 1e-4
+
+
 def test_refine_with_inputs_in_kernel_layouts(hip_lib, gpu):
     """match_and_refine fed features already in the matcher's layouts and x_d3 already in the G-Net input buffer (what
     backbones on the matrix-core path hand over) returns exactly what the NCHW-input call returns; with and without the

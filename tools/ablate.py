@@ -40,6 +40,11 @@ if os.environ.get("ABLATE_V3"):
     VARIANTS = [("v3 (2 views in flight)", V3), ("v3, 4 views in flight", V3 | (0x400000 << 8)), ("v3, 4 views, compiled for 8 waves", V3 | (0x401000 << 8)),
                 ("v3, 2 views, compiled for 8 waves", V3 | (0x1000 << 8)), ("v3, 3 correlation passes in flight", V3 | (0x40000 << 8)),
                 ("v3, 4 correlation passes in flight", V3 | (0x80000 << 8)), ("v3 without dot products", V3 | (0x200 << 8)), ("v3 again", V3)]
+if os.environ.get("ABLATE_TX"):                        # round 5: texel-pair items against the quad items of rounds 2 - 4 (dev flag 0x400), same box
+    QI = 0x400 << 8
+    VARIANTS = [("production (auto)", 0), ("same kernel, quad items (rounds 2 - 4)", QI), ("production (auto), again", 0), ("quad items, again", QI)]
+    if wl.D > 32 and wl.w <= 512:
+        VARIANTS += [("batched-view kernel (fast64), pair items", R2), ("batched-view kernel (fast64), quad items", R2 | QI)]
 if os.environ.get("ABLATE_SHORT"):
     VARIANTS = [VARIANTS[0], VARIANTS[1], VARIANTS[5], VARIANTS[6]]
 for name, path in VARIANTS:
