@@ -54,7 +54,13 @@ __global__ __launch_bounds__(256, MINW) void cv_fast64_kernel(const CvParams p) 
     // the pixels an XCD works on at any time are a band of a few rows whose source footprint (band + disparity halo, all
     // views) stays inside its 4 MiB L2 (see the launcher)
     const int NPX = p.npx;
-    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    if (p.strip_tx > 0) {                                 // vertical strips of strip_tx tiles, each walked in raster order (the last one may be narrower)
+        const int per_strip = p.strip_tx * p.tiles_y;
+        const int s = min(tile / per_strip, (p.tiles_x - 1) / p.strip_tx), r = tile - s * per_strip;
+        const int sw = min(p.strip_tx, p.tiles_x - s * p.strip_tx);
+        ty = r / sw; tx = s * p.strip_tx + (r - ty * sw);
+    }
     const int y = ty;                                     // this wave's pixel row
     const int yc = min(y, p.h - 1);
     const int x_base = (tx * 4 + wv) * NPX;
@@ -408,13 +414,23 @@ static hipError_t launch_fast64_v(const CvParams& p0, hipStream_t stream) {
     p.tiles_x = (p.w + 4 * p.npx - 1) / (4 * p.npx);
     p.tiles_y = p.h;
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
+    // Full-resolution grids (w > 512): the resident blocks of an XCD walk a 32-pixel-wide vertical strip instead of whole rows — with
+    // candidate segments ~40 texels long in both directions a 640 x 11 band of reference pixels touches 4x the source texels of a
+    // 32 x 200 strip (C2L: 2.29 -> 1.90 ms, C4L: 2.98 -> 2.79 ms with 128-pixel strips; profiles/r5/strip_order.log)
+    p.strip_tx = p.w > 512 ? 1 : 0;
+    // Texel-pair items where they pay: bf16 features (C2L 1.97 -> 1.90 ms); with fp32 features the per-view list bookkeeping costs more
+    // than the texels it saves (C4L 2.79 -> 3.09 ms), and at 3.5 items per (pixel, view) (C2, C4 grids, which cost_volume_v3.hip serves)
+    // it loses 15 - 20 %: profiles/r5/ablate_tx.log
+    bool tx = sizeof(FeatT) == 2;
 #ifdef MAGNET_DEV
-    if (p.ablate & 0x400) {                                                       // dev: quad items (rounds 2 - 4) for same-box A/B
+    { static const int strip = getenv("MAGNET_STRIP") ? atoi(getenv("MAGNET_STRIP")) : -1; if (strip >= 0) p.strip_tx = strip; }   // dev: block order A/B
+    if (p.ablate & 0x400) tx = !tx;                                               // dev: the other item form, same box
+#endif
+    if (!tx) {
         if (p.gate_bits) hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 1>), grid, block, fast64_lds_bytes(p, false), stream, p);
         else hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 0>), grid, block, fast64_lds_bytes(p, false), stream, p);
         return hipGetLastError();
     }
-#endif
     if (p.gate_bits) hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 5>), grid, block, fast64_lds_bytes(p, true), stream, p);
     else hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 4>), grid, block, fast64_lds_bytes(p, true), stream, p);
     return hipGetLastError();

@@ -36,6 +36,7 @@ struct CvParams {
     long long      cost_ld;
     uint8_t*       gate_bits;         // optional debug output (B,V,D,h,w)
     int            npx;               // cost_volume_fast64.hip: pixels per wave (set by its launcher)
+    int            strip_tx;          // cost_volume_fast64.hip: > 0 = blocks walk the frame in vertical strips of this many tiles instead of raster order
     uint32_t       magic_tiles, magic_tiles_x;   // cost_volume_v3.hip: ceil(2^32 / (tiles_x * tiles_y)), ceil(2^32 / tiles_x) (set by its launcher)
     const double*  ray_params;        // optional (B,8) fx, fy, cx, cy, sx, sy, left, top: rays generated in the kernel
     float k[MAGNET_MAX_CANDIDATES];   // (float)k_j, read with wave-uniform indices (scalar loads)

@@ -46,7 +46,7 @@ if os.environ.get("ABLATE_TX"):                        # round 5: texel-pair ite
     if wl.D > 32 and wl.w <= 512:
         VARIANTS += [("batched-view kernel (fast64), pair items", R2), ("batched-view kernel (fast64), quad items", R2 | QI)]
 if os.environ.get("ABLATE_SHORT"):
-    VARIANTS = [VARIANTS[0], VARIANTS[1], VARIANTS[5], VARIANTS[6]]
+    VARIANTS = VARIANTS[:2] if os.environ.get("ABLATE_TX") else [VARIANTS[0], VARIANTS[1], VARIANTS[5], VARIANTS[6]]
 for name, path in VARIANTS:
     if split and (path & 0xff) == 3:
         continue
