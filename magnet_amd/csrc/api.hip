@@ -238,7 +238,7 @@ MAGNET_API int magnet_cost_volume_f_backward_ws(const MagnetCostVolumeArgs* a, c
     bool ref_ok = false, src_ok = false;
     hipError_t e = magnet::launch_cvf_bwd_ref_only(p, grad_cost, grad_ref_cl, (hipStream_t)stream, &ref_ok);
     if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_f_backward_ws grad_ref launch");
-    if (ref_ok && !(p.ablate & 0x30)) {
+    if (ref_ok && !(CV_DEV(p) & 0x30)) {
         e = magnet::launch_cvf_gather_src(p, grad_cost, grad_src_pad, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes,
                                           (hipStream_t)stream, &src_ok);
         if (e != hipSuccess) return hip_fail(e, "magnet_cost_volume_f_backward_ws grad_src launch");

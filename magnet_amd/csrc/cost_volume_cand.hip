@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, MINW) void cv_cand_kernel(const CvParams p) {
     constexpr int CSTR = LPU * 16;                        // byte stride between a lane's channel chunks
     constexpr bool MODEF = VAR == 1;                      // est_costvolume_F semantics
     constexpr bool FASTV = VAR == 2;                      // production matcher: sampled candidates, no stats, no dev ablations
-    const int abl = FASTV ? 0 : p.ablate;
+    const int abl = FASTV ? 0 : CV_DEV(p);
     uint32_t* const stats = FASTV ? nullptr : p.stats;
     const float* const d_volume = FASTV ? nullptr : p.d_volume;
     constexpr int PPW = 64 / DL;
@@ -341,7 +341,7 @@ template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU = 8>
 static hipError_t launch_cand(const CvParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
     if (p.mode_f) hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 1, LPU>), grid, block, cand_lds_bytes<DL>(p), stream, p);
-    else if (!p.d_volume && !p.stats && !p.ablate && !p.gate_bits)
+    else if (!p.d_volume && !p.stats && !CV_DEV(p) && !p.gate_bits)
         hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 2, LPU>), grid, block, cand_lds_bytes<DL>(p), stream, p);
     else hipLaunchKernelGGL((cv_cand_kernel<FeatT, DL, CPL, FULL, MINW, 0, LPU>), grid, block, cand_lds_bytes<DL>(p), stream, p);
     return hipGetLastError();

@@ -412,7 +412,7 @@ hipError_t launch_cvf_bwd(const CvParams& p, const float* gout, float* grad_ref,
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
     *handled = true;
     const size_t lds_tile = (size_t)HT_SLOTS * 4 + (size_t)HT_SLOTS * 128 + 16 + (size_t)4 * (p.V * 512 + 1088 + 272 + 1088);
-    if ((p.F % 32) == 0 && lds_tile <= 80 * 1024 && !(p.ablate & 32)) {        // dev bit 32: the per-item atomic kernel
+    if ((p.F % 32) == 0 && lds_tile <= 80 * 1024 && !(CV_DEV(p) & 32)) {        // dev bit 32: the per-item atomic kernel
         hipError_t e0 = hipMemsetAsync(grad_ref, 0, (size_t)p.B * p.h * p.w * p.F * sizeof(float), stream);   // accumulated into
         if (e0 != hipSuccess) return e0;
         static bool attr_set = false;

@@ -217,7 +217,7 @@ hipError_t launch_cvf_gather_src(const CvParams& p, const float* gout, float* gr
     if (e != hipSuccess) return e;
     // 16-texel segments: 5.5 KB of LDS per wave, 28 waves per CU.  dev (path bit 14): 32-texel segments (fewer duplicated tile
     // re-projections, 16 waves per CU): 12 % slower on both training shapes; 8-texel segments were 3 - 13 % slower.
-    const int SWv = (p.ablate & 0x40) ? 32 : 16;
+    const int SWv = (CV_DEV(p) & 0x40) ? 32 : 16;
     const int segs_x = (p.w + SWv - 1) / SWv;
     const long long nunits = (long long)p.B * p.V * p.h * segs_x;
     const dim3 grid((unsigned)((nunits + 3) / 4), (unsigned)((p.F + 63) / 64));

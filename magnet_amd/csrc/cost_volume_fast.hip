@@ -331,7 +331,7 @@ template <typename FeatT, int DL, int CPL, bool FULL, int MINW, int LPU>
 static hipError_t launch_fast(const CvParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
 #ifdef MAGNET_DEV
-    if (p.ablate & 0x400) {                                                       // dev: quad items (rounds 2 - 4) for same-box A/B
+    if (CV_DEV(p) & 0x400) {                                                       // dev: quad items (rounds 2 - 4) for same-box A/B
         const size_t lq = fast_lds_bytes<DL>(p, false);
         if (p.gate_bits) hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, 2>), grid, block, lq, stream, p);
         else hipLaunchKernelGGL((cv_fast_kernel<FeatT, DL, CPL, FULL, MINW, LPU, 0>), grid, block, lq, stream, p);
@@ -341,7 +341,7 @@ static hipError_t launch_fast(const CvParams& p, hipStream_t stream) {
     size_t lds = fast_lds_bytes<DL>(p);
 #ifdef MAGNET_DEV
     {   // dev: cap the workgroups per CU by asking for more LDS than the kernel uses (occupancy sensitivity)
-        const int cap = (p.ablate & 0x300000) == 0x300000 ? 3 : (p.ablate & 0x200000) ? 4 : 0;
+        const int cap = (CV_DEV(p) & 0x300000) == 0x300000 ? 3 : (CV_DEV(p) & 0x200000) ? 4 : 0;
         if (cap) { const size_t need = (size_t)160 * 1024 / (cap + 1) + 512; if (lds < need) lds = need; }
     }
 #endif
@@ -368,15 +368,15 @@ hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled) 
     if ((size_t)(p.h + 2) * (p.w + 2) >= ((size_t)1 << 24)) return hipSuccess;               // 24-bit texel index
     if ((size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets
     if (fast_lds_bytes<64>(p) > 64 * 1024 || (p.D <= 32 && fast_lds_bytes<32>(p) > 64 * 1024)) return hipSuccess;   // absurd V (D <= 32: + the reference vectors)
-    if (p.src_gmq && !(p.ablate & 0x100)) {                                                  // D > 32 with the quad-form (mu, sigma) map: the round-3 kernel (dev bit 0x100: the round-2 kernels)
+    if (p.src_gmq && !(CV_DEV(p) & 0x100)) {                                                  // D > 32 with the quad-form (mu, sigma) map: the round-3 kernel (dev bit 0x100: the round-2 kernels)
 #ifdef MAGNET_DEV
         // round 4's two measured experiments, dev library only (profiles/r4/NOTES.md): 0x8 = quads AND texels staged in LDS by DMA, correlation on
         // the matrix pipe (cost_volume_v4.hip: 1.24 - 1.35 ms); 0x20 = round 3's kernel with the quads prefetched one unit ahead (cost_volume_v5.hip: 1.11 ms)
-        if (p.ablate & 0x8) {
+        if (CV_DEV(p) & 0x8) {
             const hipError_t e4 = launch_cv_v4(p, stream, handled);
             if (e4 != hipSuccess || *handled) return e4;
         }
-        if (p.ablate & 0x20) {
+        if (CV_DEV(p) & 0x20) {
             const hipError_t e5 = launch_cv_v5(p, stream, handled);
             if (e5 != hipSuccess || *handled) return e5;
         }
@@ -385,7 +385,7 @@ hipError_t launch_cv_fast(const CvParams& p, hipStream_t stream, bool* handled) 
         if (e != hipSuccess || *handled) return e;
     }
     if (!have_gmm) return hipSuccess;                                                         // (api.hip reports MAGNET_E_SHAPE)
-    if (!(p.ablate & 0x800)) {                                                                // D > 32: views batched per pixel (cost_volume_fast64.hip); dev 0x800: the per-view kernel below
+    if (!(CV_DEV(p) & 0x800)) {                                                                // D > 32: views batched per pixel (cost_volume_fast64.hip); dev 0x800: the per-view kernel below
         const hipError_t e = launch_cv_fast64(p, stream, handled);
         if (e != hipSuccess || *handled) return e;
     }

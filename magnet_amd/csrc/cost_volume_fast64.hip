@@ -424,7 +424,7 @@ static hipError_t launch_fast64_v(const CvParams& p0, hipStream_t stream) {
     bool tx = sizeof(FeatT) == 2;
 #ifdef MAGNET_DEV
     { static const int strip = getenv("MAGNET_STRIP") ? atoi(getenv("MAGNET_STRIP")) : -1; if (strip >= 0) p.strip_tx = strip; }   // dev: block order A/B
-    if (p.ablate & 0x400) tx = !tx;                                               // dev: the other item form, same box
+    if (CV_DEV(p) & 0x400) tx = !tx;                                               // dev: the other item form, same box
 #endif
     if (!tx) {
         if (p.gate_bits) hipLaunchKernelGGL((cv_fast64_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 1>), grid, block, fast64_lds_bytes(p, false), stream, p);

@@ -352,18 +352,18 @@ static hipError_t launch_v3_v(const CvParams& p0, hipStream_t stream) {
     size_t lds = v3_lds_bytes(p, VG);
 #ifdef MAGNET_DEV
     {   // dev: cap the workgroups per CU (waves per SIMD) by asking for more LDS than the kernel uses
-        const int cap = (p.ablate & 0x300000) == 0x300000 ? 3 : (p.ablate & 0x200000) ? 4 : (p.ablate & 0x100000) ? 5 : 0;
+        const int cap = (CV_DEV(p) & 0x300000) == 0x300000 ? 3 : (CV_DEV(p) & 0x200000) ? 4 : (CV_DEV(p) & 0x100000) ? 5 : 0;
         if (cap) { const size_t need = (size_t)160 * 1024 / (cap + 1) + 512; if (lds < need) lds = need; }
     }
 #endif
     constexpr int NP = (CPL >= 4 ? 1 : V3_NPASS_DEFAULT) << 8;     // 4 chunks per lane: one pass already has 4 wave-loads in flight
     constexpr int MW2 = CPL >= 4 ? 4 : (MINW > 5 ? 5 : MINW);             // the NCHW-output and gate-bit instances carry more live values: one wave per SIMD less instead of scratch
 #ifdef MAGNET_DEV
-    if (p.ablate & 0x200) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MW2, LPU, VG, NP | 2>), grid, block, lds, stream, p); return hipGetLastError(); }      // no dot products (timing only)
-    if (p.cost_hi && (p.ablate & 0x20000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, NP | 64 | 128>), grid, block, lds, stream, p); return hipGetLastError(); }   // dev: four-weight combine instead of the quad-form slots
-    if (p.cost_hi && (p.ablate & 0x4000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x200>), grid, block, lds, stream, p); return hipGetLastError(); }
-    if (p.cost_hi && (p.ablate & 0x40000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x300>), grid, block, lds, stream, p); return hipGetLastError(); }
-    if (p.cost_hi && (p.ablate & 0x80000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x400>), grid, block, lds, stream, p); return hipGetLastError(); }
+    if (CV_DEV(p) & 0x200) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MW2, LPU, VG, NP | 2>), grid, block, lds, stream, p); return hipGetLastError(); }      // no dot products (timing only)
+    if (p.cost_hi && (CV_DEV(p) & 0x20000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, NP | 64 | 128>), grid, block, lds, stream, p); return hipGetLastError(); }   // dev: four-weight combine instead of the quad-form slots
+    if (p.cost_hi && (CV_DEV(p) & 0x4000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x200>), grid, block, lds, stream, p); return hipGetLastError(); }
+    if (p.cost_hi && (CV_DEV(p) & 0x40000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x300>), grid, block, lds, stream, p); return hipGetLastError(); }
+    if (p.cost_hi && (CV_DEV(p) & 0x80000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x400>), grid, block, lds, stream, p); return hipGetLastError(); }
 #endif
     if (p.gate_bits) hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MW2, LPU, VG, NP | 1>), grid, block, lds, stream, p);
     else if (p.cost_hi) hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, NP | 64>), grid, block, lds, stream, p);
@@ -377,8 +377,8 @@ static hipError_t launch_v3(const CvParams& p, hipStream_t stream) {
     // alone (0.906 vs 0.879 ms per 64 C2 frames, warm) and inside the step; one view (8 waves) has too little to overlap: 0.975
     int vg = p.V == 1 ? 1 : (p.V % 2 == 0 ? 2 : (p.V % 3 == 0 ? 3 : 2));
 #ifdef MAGNET_DEV
-    if (p.ablate & 0x400000) vg = 4;                                                     // dev: views per group
-    if (p.ablate & 0x800000) vg = 1;
+    if (CV_DEV(p) & 0x400000) vg = 4;                                                     // dev: views per group
+    if (CV_DEV(p) & 0x800000) vg = 1;
 #endif
     switch (vg) {
         case 1: return launch_v3_v<FeatT, CPL, FULL, MINW, LPU, 1>(p, stream);
@@ -396,7 +396,7 @@ hipError_t launch_cv_v3(const CvParams& p, hipStream_t stream, bool* handled) {
     // Full-resolution matching grids (w > 512: the grid-stress shapes C2L / C4L, 14 instead of 3.5 items per (pixel, view)) are
     // decided by the correlation of long item lists, where the round-2 kernel (16 items per batch, one list for all views) is
     // better: C2L 2.33 vs 2.84 ms, C4L 1.54 vs 1.63 ms (same session, warm); at w <= 304 this kernel wins (C4 0.75 vs 0.95 ms)
-    if (p.w > 512 && !(p.ablate & 0x4)) return hipSuccess;                                 // dev 0x4: this kernel anyway
+    if (p.w > 512 && !(CV_DEV(p) & 0x4)) return hipSuccess;                                 // dev 0x4: this kernel anyway
     if ((size_t)p.V * p.B * (size_t)(p.h + 2) * (p.w + 2) * p.F * esz >= ((size_t)1 << 32)) return hipSuccess;   // 32-bit byte offsets over all views
     {   // quad keys carry the view offset (v * B + b's views: up to (V - 1) * B * map + map - 1) and are multiplied by the texel size
         // with a 24-bit multiply; the (mu, sigma) quad address is key << 5 in 32 bits.  Larger batches / grids go to the round-2 kernel,
@@ -415,9 +415,9 @@ hipError_t launch_cv_v3(const CvParams& p, hipStream_t stream, bool* handled) {
     // MINW = waves per SIMD the instance is compiled for: the largest that needs no scratch (78 registers for bf16 F = 64)
     if (p.feat_bf16) {
 #ifdef MAGNET_DEV
-        if (nchunk == 8 && (p.ablate & 0x1000)) return launch_v3<uint16_t, 2, true, 8, 4>(p, stream);    // dev: occupancy A/B
-        if (nchunk == 8 && (p.ablate & 0x2000)) return launch_v3<uint16_t, 2, true, 4, 4>(p, stream);
-        if (nchunk == 8 && (p.ablate & 0x10000)) return launch_v3<uint16_t, 2, true, 7, 4>(p, stream);
+        if (nchunk == 8 && (CV_DEV(p) & 0x1000)) return launch_v3<uint16_t, 2, true, 8, 4>(p, stream);    // dev: occupancy A/B
+        if (nchunk == 8 && (CV_DEV(p) & 0x2000)) return launch_v3<uint16_t, 2, true, 4, 4>(p, stream);
+        if (nchunk == 8 && (CV_DEV(p) & 0x10000)) return launch_v3<uint16_t, 2, true, 7, 4>(p, stream);
 #endif
         if (nchunk == 8)  return launch_v3<uint16_t, 2, true, 6, 4>(p, stream);          // F = 64: 4 lanes x 32 B per (item, tap) unit
         if (nchunk <= 8)  return launch_v3<uint16_t, 1, false, 6, 8>(p, stream);
@@ -426,7 +426,7 @@ hipError_t launch_cv_v3(const CvParams& p, hipStream_t stream, bool* handled) {
 #ifdef MAGNET_DEV
         // dev: 4 lanes x 64 B per unit (4 items per pass, quad-form slots) — 74 instead of 68 registers, 6 instead of 7 waves:
         // C4 0.828 vs 0.748 ms, C2 with fp32 features 1.274 vs 1.213 ms
-        if (nchunk == 16 && (p.ablate & 0x8000)) return launch_v3<float, 4, true, 5, 4>(p, stream);
+        if (nchunk == 16 && (CV_DEV(p) & 0x8000)) return launch_v3<float, 4, true, 5, 4>(p, stream);
 #endif
         if (nchunk == 16) return launch_v3<float, 2, true, 5, 8>(p, stream);             // F = 64: 8 lanes x 32 B per unit
         if (nchunk <= 8)  return launch_v3<float, 1, false, 6, 8>(p, stream);

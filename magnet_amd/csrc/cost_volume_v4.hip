@@ -386,11 +386,11 @@ hipError_t launch_cv_v4(const CvParams& p0, hipStream_t stream, bool* handled) {
     size_t lds = v4_lds_bytes(p);
     *handled = true;
 #ifdef MAGNET_DEV
-    if (p.cost_hi && (p.ablate & 0x1000)) {   // (with 0x8)                                                  // dev: 16 slots per round (6 workgroups per CU)
+    if (p.cost_hi && (CV_DEV(p) & 0x1000)) {   // (with 0x8)                                                  // dev: 16 slots per round (6 workgroups per CU)
         hipLaunchKernelGGL((cv_v4_kernel<64, 6, 16>), grid, block, v4_lds_bytes(p, 16), stream, p); return hipGetLastError();
     }
     {   // dev: cap the workgroups per CU by asking for more LDS than the kernel uses
-        const int cap = (p.ablate & 0x200000) ? 3 : (p.ablate & 0x100000) ? 4 : 0;
+        const int cap = (CV_DEV(p) & 0x200000) ? 3 : (CV_DEV(p) & 0x100000) ? 4 : 0;
         if (cap) { const size_t need = (size_t)160 * 1024 / (cap + 1) + 512; if (lds < need) lds = need; }
     }
 #endif

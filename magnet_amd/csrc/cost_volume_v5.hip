@@ -440,10 +440,10 @@ static hipError_t launch_v5_v(const CvParams& p0, hipStream_t stream) {
     size_t lds = v5_lds_bytes(p, VG);
 #ifdef MAGNET_DEV
     {   // dev: cap the workgroups per CU (waves per SIMD) by asking for more LDS than the kernel uses
-        const int cap = (p.ablate & 0x300000) == 0x300000 ? 3 : (p.ablate & 0x200000) ? 4 : (p.ablate & 0x100000) ? 5 : 0;
+        const int cap = (CV_DEV(p) & 0x300000) == 0x300000 ? 3 : (CV_DEV(p) & 0x200000) ? 4 : (CV_DEV(p) & 0x100000) ? 5 : 0;
         if (cap) { const size_t need = (size_t)160 * 1024 / (cap + 1) + 512; if (lds < need) lds = need; }
     }
-    if (p.cost_hi && (p.ablate & 0x200)) { hipLaunchKernelGGL((cv_v5_kernel<FeatT, CPL, FULL, (MINW > 5 ? 5 : MINW), LPU, VG, 2 | 64>), grid, block, lds, stream, p); return hipGetLastError(); }   // no dot products (timing only)
+    if (p.cost_hi && (CV_DEV(p) & 0x200)) { hipLaunchKernelGGL((cv_v5_kernel<FeatT, CPL, FULL, (MINW > 5 ? 5 : MINW), LPU, VG, 2 | 64>), grid, block, lds, stream, p); return hipGetLastError(); }   // no dot products (timing only)
 #endif
     constexpr int NP = (CPL >= 4 ? 1 : V5_NPASS_DEFAULT) << 8;
     constexpr int MW2 = CPL >= 4 ? 4 : (MINW > 5 ? 5 : MINW);

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, MINW) void cv_worklist_kernel(const CvParams p
                 const GmmPair g1 = *reinterpret_cast<const GmmPair*>(sgm + (qi + (uint32_t)Wp) * 8u);
                 const float mu_w = bilerp(g0.mu0, g0.mu1, g1.mu0, g1.mu1, t);
                 const float sg_w = bilerp(g0.sg0, g0.sg1, g1.sg0, g1.sg1, t);
-                const bool gate = inwin && ((__builtin_fabsf(zw - mu_w) < sg_w * p.kappa) || (p.ablate & 2));   // homography.py:157-158
+                const bool gate = inwin && ((__builtin_fabsf(zw - mu_w) < sg_w * p.kappa) || (CV_DEV(p) & 2));   // homography.py:157-158
                 // a fresh item is needed when the gate is open and the quad differs from the one held
                 const bool fresh = gate && ((int)qi != cur_q);
                 const unsigned long long bal = __ballot(fresh);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, MINW) void cv_worklist_kernel(const CvParams p
 
             // ------------------------------ P2: correlation of the wave's (item, tap) units ------------
             {
-                const int passes = (p.ablate & 1) ? 0 : (cnt + 1) >> 1;      // 2 items (8 units) per pass
+                const int passes = (CV_DEV(p) & 1) ? 0 : (cnt + 1) >> 1;      // 2 items (8 units) per pass
                 auto issue = [&](int ps, uint4 (&sv)[CPL], int& lpx) {
                     const uint32_t item = items[2 * ps + upair];
                     lpx = (int)(item >> 26);
@@ -303,7 +303,7 @@ static hipError_t launch_wl_c(const CvParams& p, hipStream_t stream, bool* handl
         // D in (32, 64] at F = 64 — the headline shapes.  Measured on MI355X (C2, 64 frames/launch):
         // bf16: R=4 @4 waves/SIMD 2.06 ms, R=4 @3 2.38, R=8 @2 2.31;  fp32: R=4 @3 2.62, R=4 @4 2.80, R=8 @2 3.30.
         // Dev overrides via ablate bits 2-3 (tools/ablate.py).
-        const int sel = (p.ablate >> 2) & 3;
+        const int sel = (CV_DEV(p) >> 2) & 3;
         if (sel == 1) return launch_wl<FeatT, 4, 4, CPL, FULL, 3>(p, stream);
         if (sel == 2) return launch_wl<FeatT, 4, 4, CPL, FULL, 4>(p, stream);
         if (sel == 3) return launch_wl<FeatT, 8, 2, CPL, FULL, 2>(p, stream);

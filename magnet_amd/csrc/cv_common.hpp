@@ -16,7 +16,7 @@ struct CvParams {
     int tiles_x, tiles_y;
     int feat_bf16;
     int mode_f;                       // 1 = est_costvolume_F semantics (fixed bins, no gate, fp32 view sum)
-    int ablate;                       // MagnetCostVolumeArgs.dev_flags (0 unless built with -DMAGNET_DEV): timing ablations / kernel variants
+    int ablate;                       // MagnetCostVolumeArgs.dev_flags, dev library only — read through CV_DEV(p) below, never directly
     float kappa;
     const void*    ref_feat;
     const void*    src_feat;          // (V*B, h+2, w+2, F) channel-last, one-texel zero border
@@ -41,6 +41,14 @@ struct CvParams {
     const double*  ray_params;        // optional (B,8) fx, fy, cx, cy, sx, sy, left, top: rays generated in the kernel
     float k[MAGNET_MAX_CANDIDATES];   // (float)k_j, read with wave-uniform indices (scalar loads)
 };
+
+// Development switches (timing ablations, kernel variants for same-box A/B: tools/README.md).  The product library is compiled without
+// MAGNET_DEV: every CV_DEV(p) is the constant 0 there and the branches it guards are removed by the compiler.
+#ifdef MAGNET_DEV
+#define CV_DEV(p) ((p).ablate)
+#else
+#define CV_DEV(p) 0
+#endif
 
 __device__ __forceinline__ GridConst grid_const(const CvParams& p) {
     GridConst gc;

@@ -13,7 +13,7 @@
 #   ablate_*.log          matcher variants on the dev library (tools/ablate.py), issue_rate / gather_rate microbenchmarks
 # Every profiler pass has a short timeout: some TA/TCP/TD counter sets hang rocprofv3 on this pool.  The --pmc passes run the
 # contract's own 5 + 20 steps, so that the clock / busy counters describe the chip state the bench line was measured in.
-tag=${1:-r4}
+tag=${1:-r5}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$tag; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
@@ -56,10 +56,9 @@ timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fvolume_s
 timeout 200 python tools/bench_end_to_end.py > $O/bench_end_to_end.json 2> $O/bench_end_to_end.err
 timeout 200 python tools/bench_pipeline.py 2>/dev/null | tail -1 > $O/bench_pipeline.json
 # matcher variants (dev library) + instruction / gather microbenchmarks
-timeout 150 python tools/ablate.py C2 64 split > $O/ablate_C2_split.log 2>&1
-timeout 150 python tools/ablate.py C2 64 > $O/ablate_C2_nchw.log 2>&1
-timeout 100 python tools/conv_kscale.py 2>/dev/null > $O/conv_kscale.log
-for u in issue_rate gather_rate mx_split dma_rate pp_barrier; do
+ABLATE_TX=1 timeout 150 python tools/ablate.py C2 64 split 2>&1 | grep -v amdgpu.ids > $O/ablate_C2_split.log
+for cfg in "C2L 4" "C4L 4" "shipped 64" "C1 64"; do set -- $cfg; ABLATE_TX=1 timeout 200 python tools/ablate.py $1 $2 split 2>&1 | grep -v amdgpu.ids >> $O/ablate_tx.log; done
+for u in issue_rate gather_rate; do
   [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2>/dev/null
   timeout 120 tools/ubench/$u > $O/$u.txt 2>&1
 done
