@@ -159,6 +159,33 @@ def test_full_resolution_grids_vs_oracle(hip_lib, gpu, name, fdt):
     assert st["gate_flip_frac"] <= 1e-5 * flip_scale(wl.h, wl.w)        # the contract rate scales with the grid (tests/parity.py: flip_scale)
 
 
+def _axis_poses(B, V, step):
+    """Pure translations along +x, -x, +y, -y (repeating), no rotation: the candidates of a pixel travel along one image axis, in both
+    directions — the four (mode, direction) cases of the texel-pair item lists (cost_volume_fast.hip / cost_volume_fast64.hip)."""
+    poses = torch.eye(4).repeat(B, V, 1, 1)
+    for v in range(V):
+        poses[:, v, v // 2 % 2, 3] = step * (1.0 if v % 2 == 0 else -1.0) * (1.0 + 0.25 * (v // 4))
+    return poses
+
+
+@pytest.mark.parametrize("name,h,w,V,D,F,fdt,step", [
+    ("D16 per-view kernel", 24, 40, 4, 16, 64, "fp32", 0.25),
+    ("D5 per-view kernel, bf16", 20, 36, 4, 5, 32, "bf16", 0.4),
+    ("D64 batched views, wide grid, bf16 pair items", 10, 528, 4, 64, 64, "bf16", 2.0),
+    ("D64 batched views, wide grid, fp32 quad items", 10, 528, 4, 64, 64, "fp32", 2.0),
+    ("D128 long segments, table overflow -> view by view", 6, 640, 8, 128, 64, "bf16", 6.0),
+])
+def test_pair_items_all_travel_directions(hip_lib, gpu, name, h, w, V, D, F, fdt, step):
+    """Round 5: texel-pair items.  Source views translated along +x / -x / +y / -y make every (row / column mode, up / down direction)
+    case of the shared-pair bookkeeping run in one launch; a long baseline with wide sigma stretches the segments over many quads (the
+    last case makes a view group need more than the 128 table entries, i.e. the view-by-view path).  Same tolerance contract."""
+    wl = synth.Workload("axes", "scannet", h, w, V=V, D=D, F=F)
+    inp = synth.make_inputs(wl, B=2, seed=17, round_bf16=(fdt == "bf16"), invalid=[(1, 1)])
+    inp["nghbr_poses"] = _axis_poses(2, V, step)
+    inp["ref_gmms"][:, 1] *= 2.0                                      # wider candidate spread: more distinct quads per pixel
+    _check(inp, oracle.depth_sampling(3, D), gpu, fdt=fdt, label=name)
+
+
 def test_large_batch_key_range(hip_lib, gpu):
     """launch_cv_v3 declines batches whose quad keys over all views of a frame ((V - 1) * B * map + map) do not fit its 24-bit
     multiply: V = 4, 30 x 40 grid (map = 1344), B = 4200 -> 1.69e7 > 2^24, so the call falls to the round-2 kernel,
