@@ -230,6 +230,28 @@ def live_conv_counters(a, timeout_s=120):
             "source": "live rocprofv3 --pmc pass over this step: mean over all conv_mfma_kernel dispatches"}
 
 
+_RESULT_FD = None
+
+
+def _claim_stdout():
+    """The contract: rank 0's stdout carries ONE JSON line and nothing else.  Native libraries print to fd 1 behind Python's back (RCCL
+    writes a five-line version banner to stdout when a process group is created): keep a private duplicate of the real stdout for the
+    result line and point fd 1 at stderr for everything else.  Idempotent."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit_result(obj) -> None:
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
+
 def _bound_label(binding, traffic, kern_ms):
     """What binds the fused kernel according to the live counters: "hbm" only if its measured HBM traffic runs at more than half of the
     peak rate; otherwise the busier of its two issue pipes, and "latency" when neither is above 85 % (waves waiting on dependent loads).
@@ -325,7 +347,7 @@ def dry_run(a, rank, world):
     per_rank = mdist.gather_floats((hi - lo) * a.steps / max(mine, 1e-9))
     frames = mdist.sum_over_ranks(hi - lo)
     if rank == 0:
-        print(json.dumps({"metric": "dry-run (launcher self-test, no kernels)", "value": None, "unit": "ref-frames/s",
+        _emit_result({"metric": "dry-run (launcher self-test, no kernels)", "value": None, "unit": "ref-frames/s",
                           "per_rank_frames_per_s": per_rank,
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / max(1, a.steps),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -334,7 +356,7 @@ def dry_run(a, rank, world):
                           "weight_broadcast_bytes": bcast_bytes, "fnet_weight_broadcast_bytes": fnet_bytes,
                           "rccl": {"world": world, "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                                    "broadcast_bytes": bcast_bytes + fnet_bytes, "broadcast_verified": bcast_ok},
-                          "cpus_per_rank": [int(v) for v in n_cpus]}))
+                          "cpus_per_rank": [int(v) for v in n_cpus]})
     mdist.barrier()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
@@ -381,6 +403,7 @@ def main():
         # DDP workers the same way, train_MaGNet.py:323-338); under torch.distributed.run the environment is already set
         raise SystemExit(spawn_ranks(a.gpus))
 
+    _claim_stdout()
     if os.environ.get("MAGNET_BENCH_FAIL_RANK") == os.environ.get("RANK", "0") and a.dry_run:
         raise SystemExit(3)                                  # launcher self-test (tests/test_bench_launcher.py): this rank dies early
     rccl = {"world": 1, "backend": None, "broadcast_bytes": 0, "broadcast_verified": None}
@@ -653,7 +676,7 @@ def main():
                 res["roofline_conv"].update(conv_binding)
         if model_cpu is not None:
             res["cpu_baseline"] = cpu_baseline(wl, model_cpu, iters)
-        print(json.dumps(res))
+        _emit_result(res)
     mdist.barrier()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

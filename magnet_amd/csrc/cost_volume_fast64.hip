@@ -414,10 +414,12 @@ static hipError_t launch_fast64_v(const CvParams& p0, hipStream_t stream) {
     p.tiles_x = (p.w + 4 * p.npx - 1) / (4 * p.npx);
     p.tiles_y = p.h;
     const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * p.B)), block(256);
-    // Full-resolution grids (w > 512): the resident blocks of an XCD walk a 32-pixel-wide vertical strip instead of whole rows — with
-    // candidate segments ~40 texels long in both directions a 640 x 11 band of reference pixels touches 4x the source texels of a
-    // 32 x 200 strip (C2L: 2.29 -> 1.90 ms, C4L: 2.98 -> 2.79 ms with 128-pixel strips; profiles/r5/strip_order.log)
-    p.strip_tx = p.w > 512 ? 1 : 0;
+    // Full-resolution grids (w > 512): the resident blocks of an XCD walk a narrow vertical strip instead of whole rows — with candidate
+    // segments ~40 texels long in both directions a 640 x 11 band of reference pixels touches twice the source texels of a 32 x 200
+    // strip.  Measured per strip width (profiles/r5/strip_sweep.log, kernel alone, warm): 480 x 640 ScanNet grids 32-pixel strips
+    // (C2L 2.30 -> 1.90 ms, fp32 features 2.25 -> 1.40 ms; 64 / 128 / 256 pixels: 1.93 / 1.97 / 2.00); the 352 x 1216 KITTI grid (forward
+    // motion: radial segments, no preferred direction) hardly cares: 1.53 raster, 1.57 / 1.56 / 1.53 / 1.49 ms at 32 / 64 / 128 / 256 pixels
+    p.strip_tx = p.w > 1024 ? 8 : (p.w > 512 ? 1 : 0);
     // Texel-pair items where they pay: bf16 features (C2L 1.97 -> 1.90 ms); with fp32 features the per-view list bookkeeping costs more
     // than the texels it saves (C4L 2.79 -> 3.09 ms), and at 3.5 items per (pixel, view) (C2, C4 grids, which cost_volume_v3.hip serves)
     // it loses 15 - 20 %: profiles/r5/ablate_tx.log

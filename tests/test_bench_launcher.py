@@ -15,9 +15,9 @@ def _run(args, env=None):
     e.update(env or {})
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    return json.loads(lines[0])
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout    # the contract: ONE JSON line on stdout and nothing else (native
+    return json.loads(lines[0])                                        # libraries' banners — RCCL prints one — are routed to stderr)
 
 
 def test_bench_spawns_two_ranks_dry_run():

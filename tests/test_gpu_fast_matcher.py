@@ -160,11 +160,17 @@ def test_full_resolution_grids_vs_oracle(hip_lib, gpu, name, fdt):
 
 
 def _axis_poses(B, V, step):
-    """Pure translations along +x, -x, +y, -y (repeating), no rotation: the candidates of a pixel travel along one image axis, in both
-    directions — the four (mode, direction) cases of the texel-pair item lists (cost_volume_fast.hip / cost_volume_fast64.hip)."""
+    """Translations along +x, -x, +y, -y (repeating), no rotation: the candidates of a pixel travel along one image axis, in both
+    directions — the four (mode, direction) cases of the texel-pair item lists (cost_volume_fast.hip / cost_volume_fast64.hip).  A 7 %
+    component along the other axis slants the segments a little: with an exactly axis-parallel translation every sample would sit ON a
+    texel boundary of the other axis (v = y + 0.5 for all depths), where a 1-ulp difference picks the other quad and the
+    position-sensitivity model of tests/parity.py (the slope inside the oracle's quad) does not describe the difference."""
     poses = torch.eye(4).repeat(B, V, 1, 1)
     for v in range(V):
-        poses[:, v, v // 2 % 2, 3] = step * (1.0 if v % 2 == 0 else -1.0) * (1.0 + 0.25 * (v // 4))
+        major = v // 2 % 2
+        sgn = step * (1.0 if v % 2 == 0 else -1.0) * (1.0 + 0.25 * (v // 4))
+        poses[:, v, major, 3] = sgn
+        poses[:, v, 1 - major, 3] = 0.07 * sgn * (1.0 if v % 3 else -1.0)
     return poses
 
 
