@@ -151,9 +151,13 @@ def _pmc_passes(passes, child_args, kernel_match, timeout_s=90):
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", tmp, "-o", "p", "--",
                sys.executable, os.path.abspath(__file__), "--no-pmc", "--no-cpu-baseline", "--sustain-s", "0", *child_args]
         try:
-            env = dict(os.environ, TMPDIR="/tmp")
-            for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-                env.pop(k_, None)
+            # a clean single-process environment for the child: under torchrun the parent's rendezvous variables (and
+            # TORCHELASTIC_USE_AGENT_STORE, which makes env:// rendezvous a CLIENT of the agent's store) would make the child's own
+            # one-rank group wait for a store that does not exist until the pass times out
+            env = {k_: v_ for k_, v_ in os.environ.items()
+                   if not (k_.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "GROUP_", "ROLE_")) or
+                           k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK"))}
+            env["TMPDIR"] = "/tmp"
             # own session: on a timeout the whole group (profiler + the python it started) is stopped, not only the profiler
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:

@@ -36,8 +36,12 @@ def init_from_env(backend: str | None = None, always: bool = False):
     (train_MaGNet.py:197-210 is the reference's pattern).  Without `always` a plain launch stays single-process."""
     rank, world, local = env_world()
     if (world > 1 or "RANK" in os.environ or always) and not dist.is_initialized():
+        if "RANK" not in os.environ:                       # our own one-rank group: never a client of somebody else's store
+            os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(_free_port())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533" if "RANK" in os.environ else str(_free_port()))
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
