@@ -45,6 +45,12 @@ constexpr int CV_ROW = 64;                            // bytes per staged row (3
 // 80-byte padded rows: SQ_LDS_BANK_CONFLICT was 50 % of SQ_LDS_IDX_ACTIVE.
 __device__ __forceinline__ int cv_swz(int row, int slot) { return row * CV_ROW + ((slot ^ ((row >> 1) & 3)) << 4); }
 
+// The same image for the 32x32x16 fragment pattern (lane -> row = lane & 31, K slot = 2 * half + (lane >> 5)): the ds_read_b128 lane
+// groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (and their upper-half twins) then hold, per residue of row mod 4, four rows that differ
+// in bits 2..3 (0/12/20/24, 4/8/16/28, ... — also after a shift by a tap offset), so XOR-ing the slot with (row >> 2) & 3 spreads them
+// over the four 16-byte slots of the 64-bank window; (row >> 1) & 3 above would put rows 0 and 8 on the same banks.
+__device__ __forceinline__ int cv_swz32(int row, int slot) { return row * CV_ROW + ((slot ^ ((row >> 2) & 3)) << 4); }
+
 __device__ __forceinline__ uint16_t bf16_rne(float f) { return f32_to_bf16_rne(f); }     // v_cvt_pk_bf16_f32 (warp_math.hpp)
 __device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) {
     hi = bf16_rne(x);
@@ -325,6 +331,13 @@ __device__ __forceinline__ void tail_layer_cols(const uint16_t* __restrict__ w_h
 // One MFMA of the K loop.  SWAP (kernels with a fused tail): operands exchanged, so the accumulator holds C^T — a lane has 4
 // consecutive output CHANNELS of one row, and the tail's activation tile is written with packed conversions and 8-byte LDS stores
 // (the plain orientation gives 4 consecutive rows of one channel: 128 two-byte stores per lane and tile).
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+// 32x32x16 form, operands swapped as in the fused-tail kernels (weights = A operand): C^T block [32 channels][32 tile rows]; lane l,
+// register i: channel (i & 3) + 8 * (i >> 2) + 4 * (l >> 5), tile row l & 31 (cdna_hip_programming.md, fragment layout)
+__device__ __forceinline__ f32x16_t cv_mma32(const bf16x8_t& act, const bf16x8_t& wgt, const f32x16_t& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt, act, c, 0, 0, 0);
+}
+
 template <bool SWAP>
 __device__ __forceinline__ f32x4_t cv_mma(const bf16x8_t& a, const bf16x8_t& b, const f32x4_t& c) {
     if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
@@ -348,12 +361,20 @@ __device__ __forceinline__ f32x4_t cv_mma(const bf16x8_t& a, const bf16x8_t& b, 
 // (64 v_accvgpr_read + 64 v_accvgpr_write) on every trip of the K loop.
 // One output tile (CV_BM rows x BN channels).  `bid` of `n_tiles`: the tile's position in launch order (the block id of a one-tile-per-
 // workgroup launch, the loop counter of a persistent one); `by`: the channel block.
-template <int NF, int WN, int CV_BM, int SPB, int TAIL, int NT, bool PP, int WIN>
+// M32_ (round 5, DEV ONLY — MAGNET_CONV_VARIANT=16384): the fused-tail kernels' register-window loops (WIN == 2, with and without
+// ping-pong) on v_mfma_f32_32x32x16_bf16 — a wave's 64 x 64 tile as 2 x 2 blocks of 32 x 32 instead of 4 x 4 of 16 x 16: the same
+// MACs, fragment reads, registers and (by the guide's lane-group model) conflict-free LDS reads with the cv_swz32 image.  The bet: the
+// kernel is power-limited and the guide's microbenchmark floors are 2 382 TF for the 32x32 shape against 2 075 TF for 16x16.  Parity
+// green (tests/test_gpu_conv.py), measured 5.5 % SLOWER on both stacks (2.135 vs 2.02 ms per 3x3 launch, profiles/r5/conv_m32_ab.log):
+// the 32x32x16 shape halves the operand reads per MAC but doubles the fp32 accumulator traffic (K = 16 per instruction): 0.625 against
+// 0.5 register bytes per MAC.  Kept as a record; the product library does not instantiate it.
+template <int NF, int WN, int CV_BM, int SPB, int TAIL, int NT, bool PP, int WIN, bool M32_ = false>
 __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsigned bid, const unsigned n_tiles, const unsigned by, const int tid) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins do not exist in the host pass (which only needs the stub)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // ring of 2*SPB stages (declared here, not passed in: a pointer
                                                                             // parameter is a generic pointer, and its casts to LDS pointers get null checks)
     constexpr int BN = NF * 16;
+    constexpr bool M32 = M32_ && TAIL > 0 && NF == 8 && WN == 2 && WIN == 2;
     constexpr int RP = NT / 4;                        // tile rows filled by one DMA instruction per wave set (4 lanes per 64-byte row)
     constexpr int A_PT = CV_BM / RP;                           // 16-byte vectors per thread per A plane (2 or 4)
     constexpr int WM = (NT / 64) / WN;                // waves along M
@@ -383,7 +404,7 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsign
     const int ksteps_per_tap = p.cin / CV_BK;
     const int nsteps = p.taps * ksteps_per_tap;
     const int st_r = tid >> 2, st_q = tid & 3;
-    const int st_k = (st_q ^ ((st_r >> 1) & 3)) * 8;           // logical K offset (elements) this lane fetches
+    const int st_k = (st_q ^ (M32 ? ((st_r >> 2) & 3) : ((st_r >> 1) & 3))) * 8;   // logical K offset (elements) this lane fetches (cv_swz / cv_swz32)
     const int wave_row = __builtin_amdgcn_readfirstlane(wv * 16);   // first tile row this wave's DMA instruction fills
 
     // step order: K-chunk outer, tap inner — the 9 taps of one 32-channel chunk re-read (shifted) the same 64-byte
@@ -437,15 +458,36 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsign
         if (++pf_tx == p.tap_n) { pf_tx = 0; if (++pf_ty == p.tap_n) { pf_ty = 0; pf_tap = 0; pf_k0 += CV_BK; } }   \
     }
 
-    f32x4_t acc[MF][NFW];
+    f32x4_t acc[MF][NFW];                                      // (dead in the M32 instances)
+    f32x16_t acc32[M32 ? 2 : 1][M32 ? 2 : 1];                  // M32: [row block of 32][channel block of 32] of the wave's 64 x 64 tile
 #pragma unroll
     for (int m = 0; m < MF; ++m)
 #pragma unroll
         for (int n = 0; n < NFW; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < (M32 ? 2 : 1); ++m)
+#pragma unroll
+        for (int n = 0; n < (M32 ? 2 : 1); ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc32[m][n][i] = 0.f;
     // fused-tail kernels (C^T accumulators: 4 consecutive channels of one row per lane): the loop-invariant partial sums of the
     // hoisted G-Net layer (ConvParams::addend) are the accumulators' INITIAL value — sixteen 16-byte loads whose latency hides
     // behind the K loop's prologue instead of sitting exposed in the epilogue (the short K = 288 / 576 per-iteration layers)
-    if constexpr (TAIL > 0) {
+    if constexpr (M32) {
+        if (p.addend) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const long long row = row0 + wm * 64 + mb * 32 + (lane & 31);
+                        const int ch = wn * 64 + nb * 32 + g4 * 8 + (lane >> 5) * 4;
+                        const float4 a4 = *reinterpret_cast<const float4*>(p.addend + (size_t)(row < p.rows ? row : p.rows - 1) * p.addend_ld + ch);
+                        acc32[mb][nb][g4 * 4 + 0] = a4.x; acc32[mb][nb][g4 * 4 + 1] = a4.y; acc32[mb][nb][g4 * 4 + 2] = a4.z; acc32[mb][nb][g4 * 4 + 3] = a4.w;
+                    }
+        }
+    } else if constexpr (TAIL > 0) {
         if (p.addend) {
 #pragma unroll
             for (int m = 0; m < MF; ++m)
@@ -1113,6 +1155,14 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsign
         int a_offx[3];
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) a_offx[tx] = cv_swz(wm * (MF * 16) + frow + tx * p.tap_sx, lane >> 4);
+        // M32: fragment (row block mb, K half h) of the window at tap tx / of the weight tile: index mb * 2 + h of the same register arrays
+        int a_offx32[3][2], b_off32[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) a_offx32[tx][h] = cv_swz32(wm * 64 + (lane & 31) + tx * p.tap_sx, 2 * h + (lane >> 5));
+            b_off32[h] = cv_swz32(wn * 64 + (lane & 31), 2 * h + (lane >> 5));
+        }
         bf16x8_t ah[3][MF], al[3][MF], fbh[NFW], fbl[NFW];
 #ifdef CONV_ABL      // ablation builds: LDS reads by 32-bit address (a conditional read through the generic pointer trips a backend bug: null check of the LDS cast)
         typedef uint32_t cv_u32x4 __attribute__((ext_vector_type(4)));
@@ -1123,14 +1173,66 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsign
         auto load_b = [&](int slot) {
             const unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
             const unsigned char* sb_lo = sb_hi + B_BYTES;
+            if constexpr (M32) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        fbh[nb * 2 + h] = __builtin_bit_cast(bf16x8_t, CV_LD16(sb_hi + b_off32[h] + nb * 32 * CV_ROW));
+                        fbl[nb * 2 + h] = __builtin_bit_cast(bf16x8_t, CV_LD16(sb_lo + b_off32[h] + nb * 32 * CV_ROW));
+                    }
+                return;
+            }
 #pragma unroll
             for (int n = 0; n < NFW; ++n) {
                 fbh[n] = __builtin_bit_cast(bf16x8_t, CV_LD16(sb_hi + b_off + n * 16 * CV_ROW));
                 fbl[n] = __builtin_bit_cast(bf16x8_t, CV_LD16(sb_lo + b_off + n * 16 * CV_ROW));
             }
         };
+        auto load_win = [&]() {
+            if constexpr (M32) {
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            ah[tx][mb * 2 + h] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + a_offx32[tx][h] + mb * 32 * CV_ROW));
+                            al[tx][mb * 2 + h] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + A_BYTES + a_offx32[tx][h] + mb * 32 * CV_ROW));
+                        }
+                return;
+            }
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int m = 0; m < MF; ++m) {
+                    ah[tx][m] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + a_offx[tx] + m * 16 * CV_ROW));
+                    al[tx][m] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + A_BYTES + a_offx[tx] + m * 16 * CV_ROW));
+                }
+        };
         auto mfmas = [&](const bf16x8_t (&xh)[MF], const bf16x8_t (&xl)[MF]) {
             __builtin_amdgcn_s_setprio(1);
+            if constexpr (M32) {
+                // small terms first; consecutive MFMAs write different accumulators (4 blocks between two updates of one)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) acc32[mb][nb] = cv_mma32(xl[mb * 2 + h], fbh[nb * 2 + h], acc32[mb][nb]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) acc32[mb][nb] = cv_mma32(xh[mb * 2 + h], fbl[nb * 2 + h], acc32[mb][nb]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) acc32[mb][nb] = cv_mma32(xh[mb * 2 + h], fbh[nb * 2 + h], acc32[mb][nb]);
+            } else {
 #if defined(CONV_ABL) && (CONV_ABL & 8)
             if (false)
 #endif
@@ -1142,6 +1244,7 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsign
                 for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xh[m], fbl[n], acc[m][n]);
 #pragma unroll
                 for (int m = 0; m < MF; ++m) acc[m][n] = cv_mma<(TAIL > 0)>(xh[m], fbh[n], acc[m][n]);
+            }
             }
             __builtin_amdgcn_s_setprio(0);
             asm volatile("" ::: "memory");
@@ -1164,28 +1267,13 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsign
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BP) : "memory");                 // window 0 and stage 0 landed (this wave's pieces)
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier (= half a sub-step) behind group 0
-        if constexpr (abl_a) {
-#pragma unroll
-            for (int tx = 0; tx < 3; ++tx)
-#pragma unroll
-                for (int m = 0; m < MF; ++m) {
-                    ah[tx][m] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + a_offx[tx] + m * 16 * CV_ROW));
-                    al[tx][m] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + A_BYTES + a_offx[tx] + m * 16 * CV_ROW));
-                }
-        }
+        if constexpr (abl_a) load_win();
         if constexpr (abl_b) load_b(0);
         for (int g = 0; g < ngroups; ++g) {
             const bool lastg = g + 1 == ngroups;
             // ---- tx = 0 ----
             asm volatile("" ::: "memory");
-            if constexpr (!abl_a)
-#pragma unroll
-            for (int tx = 0; tx < 3; ++tx)
-#pragma unroll
-                for (int m = 0; m < MF; ++m) {
-                    ah[tx][m] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + a_offx[tx] + m * 16 * CV_ROW));
-                    al[tx][m] = __builtin_bit_cast(bf16x8_t, CV_LD16(a_win + A_BYTES + a_offx[tx] + m * 16 * CV_ROW));
-                }
+            if constexpr (!abl_a) load_win();
             if constexpr (!abl_b) load_b(0);
             if constexpr (!abl_dma) dma_b(2);                           // stage 3g + 2
             CV_END_LOAD(BP)                                   // stage 3g + 1 landed
@@ -1266,11 +1354,46 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsign
         int a_offx[3];
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) a_offx[tx] = cv_swz(wm * (MF * 16) + frow + tx * p.tap_sx, lane >> 4);
+        int a_offx32[3][2], b_off32[2];                      // M32: see the ping-pong loop above
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) a_offx32[tx][h] = cv_swz32(wm * 64 + (lane & 31) + tx * p.tap_sx, 2 * h + (lane >> 5));
+            b_off32[h] = cv_swz32(wn * 64 + (lane & 31), 2 * h + (lane >> 5));
+        }
         bf16x8_t ah[3][MF], al[3][MF];
         auto mfma_b = [&](int slot, const bf16x8_t (&xh)[MF], const bf16x8_t (&xl)[MF]) {
             const unsigned char* sb_hi = b_ring + slot * (2 * B_BYTES);
             const unsigned char* sb_lo = sb_hi + B_BYTES;
             bf16x8_t fbh[NFW], fbl[NFW];
+            if constexpr (M32) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        fbh[nb * 2 + h] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off32[h] + nb * 32 * CV_ROW));
+                        fbl[nb * 2 + h] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_lo + b_off32[h] + nb * 32 * CV_ROW));
+                    }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) acc32[mb][nb] = cv_mma32(xl[mb * 2 + h], fbh[nb * 2 + h], acc32[mb][nb]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) acc32[mb][nb] = cv_mma32(xh[mb * 2 + h], fbl[nb * 2 + h], acc32[mb][nb]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) acc32[mb][nb] = cv_mma32(xh[mb * 2 + h], fbh[nb * 2 + h], acc32[mb][nb]);
+                return;
+            }
 #pragma unroll
             for (int n = 0; n < NFW; ++n) {
                 fbh[n] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb_hi + b_off + n * 16 * CV_ROW));
@@ -1299,6 +1422,17 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsign
             // ---- tx = 0: stage 3g (slot 0) and window g have landed; refill slot 2 with stage 3g + 2 ----
             CV_WAIT_BARRIER(BP)
             dma_b(2);
+            if constexpr (M32) {
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            ah[tx][mb * 2 + h] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + a_offx32[tx][h] + mb * 32 * CV_ROW));
+                            al[tx][mb * 2 + h] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + A_BYTES + a_offx32[tx][h] + mb * 32 * CV_ROW));
+                        }
+            } else {
 #pragma unroll
             for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
@@ -1306,6 +1440,7 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsign
                     ah[tx][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + a_offx[tx] + m * 16 * CV_ROW));
                     al[tx][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a_win + A_BYTES + a_offx[tx] + m * 16 * CV_ROW));
                 }
+            }
             mfma_b(0, ah[0], al[0]);
             // ---- tx = 1: every wave holds window g in registers (lgkmcnt(0) before the barrier): fetch window g + 1 ----
             CV_WAIT_BARRIER(BP)
@@ -1489,6 +1624,29 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsign
                       "the fused tail is written for 128-channel tiles with 32 rows per wave");
         unsigned char* act_hi = smem;                                   // [CV_BM rows][256 B]; the K ring is dead (barrier above)
         unsigned char* act_lo = smem + CV_BM * 256;
+        if constexpr (M32) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {          // C^T blocks (cv_mma32): registers 4 g4 .. 4 g4 + 3 = 4 consecutive channels of one row
+                        const int trow = wm * 64 + mb * 32 + (lane & 31);
+                        const int ch = wn * 64 + nb * 32 + g4 * 8 + (lane >> 5) * 4;
+                        float v[4] = {acc32[mb][nb][g4 * 4 + 0], acc32[mb][nb][g4 * 4 + 1], acc32[mb][nb][g4 * 4 + 2], acc32[mb][nb][g4 * 4 + 3]};
+                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch);
+                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                        if (p.relu) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];
+                        }
+                        uint32_t h01, l01, h23, l23;
+                        split_bf16x2(v[0], v[1], h01, l01); split_bf16x2(v[2], v[3], h23, l23);
+                        const int off = act_swz(trow, ch >> 3) + (ch & 7) * 2;
+                        *reinterpret_cast<uint2*>(act_hi + off) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(act_lo + off) = make_uint2(l01, l23);
+                    }
+        } else
 #pragma unroll
         for (int m = 0; m < MF; ++m)
 #pragma unroll
@@ -1653,7 +1811,7 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const unsign
 // 1.604 ms at K = 9 x 256, 2.134 vs 2.118 / 1.950 vs 1.914 ms on the two fused-tail stacks — the hardware's own relaunch already costs
 // nothing; the fixed part is the tile's exposed first-stage DMA latency, the ping-pong ramp and the epilogue, which only a next-tile
 // prefetch issued BEFORE the epilogue could hide (LDS for it exists only in the TAIL = 0 kernel).  Kept for that experiment.
-template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, int WIN = 0, bool PERSIST = false>
+template <int NF, int WN, int CV_BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, int WIN = 0, bool PERSIST = false, bool M32 = false>
 __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
     if constexpr (PERSIST) {
         const unsigned n_tiles = (unsigned)((p.rows + CV_BM - 1) / CV_BM);     // (loop-invariant hoisting is the trap of this form: see below)
@@ -1666,13 +1824,13 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const ConvParams p) {
             // the same for each tile, and hoisted out of the loop they would all be live across it
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
-            conv_mfma_tile<NF, WN, CV_BM, SPB, TAIL, NT, PP, WIN>(q, t, n_tiles, blockIdx.y, tid);
+            conv_mfma_tile<NF, WN, CV_BM, SPB, TAIL, NT, PP, WIN, M32>(q, t, n_tiles, blockIdx.y, tid);
             // the epilogue's LDS reads (staging rows, the tail's activation tile) retire before any wave's next-tile DMA lands
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
     } else {
-        conv_mfma_tile<NF, WN, CV_BM, SPB, TAIL, NT, PP, WIN>(p, blockIdx.x, gridDim.x, blockIdx.y, threadIdx.x);
+        conv_mfma_tile<NF, WN, CV_BM, SPB, TAIL, NT, PP, WIN, M32>(p, blockIdx.x, gridDim.x, blockIdx.y, threadIdx.x);
     }
 }
 
@@ -1698,7 +1856,7 @@ static int conv_cu_count() {
     return n;
 }
 
-template <int NF, int WN, int BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, int WIN = 0, bool PERSIST = false>
+template <int NF, int WN, int BM, int SPB, int TAIL = 0, int NT = 256, bool PP = false, int WIN = 0, bool PERSIST = false, bool M32 = false>
 static hipError_t launch_conv_nf(const ConvParams& p, hipStream_t s) {
     dim3 grid((unsigned)((p.rows + BM - 1) / BM), (unsigned)(p.cout_pad / (NF * 16))), block(NT);
     size_t lds = conv_lds_bytes<NF, WN, BM, SPB, NT, PP, WIN>();
@@ -1712,11 +1870,11 @@ static hipError_t launch_conv_nf(const ConvParams& p, hipStream_t s) {
     }
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {          // > 64 KiB of dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP, WIN, PERSIST>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP, WIN, PERSIST, M32>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP, WIN, PERSIST>), grid, block, lds, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<NF, WN, BM, SPB, TAIL, NT, PP, WIN, PERSIST, M32>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
@@ -1777,11 +1935,25 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
                 if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true, 2, true>(p, s);
             }
 #endif
+#ifdef MAGNET_DEV
+            if (p.variant & 16384) {                            // dev (MAGNET_CONV_VARIANT=16384): round 5's 32x32x16 form (M32_), measured 5.5 % SLOWER
+                if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 2, false, true>(p, s);
+                if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 2, false, true>(p, s);
+                if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true, 2, false, true>(p, s);
+            }
+#endif
             if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 256, 1, 1, 512, true, 2>(p, s);
             if (p.tail_cout == 128) return launch_conv_nf<8, 2, 256, 1, 8, 512, true, 2>(p, s);
             if (p.tail_cout == 144) return launch_conv_nf<8, 2, 256, 1, 9, 512, true, 2>(p, s);
         }
         if (win && p.tap_n == 3 && !(p.variant & 8)) {          // dev (MAGNET_CONV_VARIANT=8): the 2-slot window loop below
+#ifdef MAGNET_DEV
+            if (p.variant & 16384) {                            // (the 4-wave kernel in the same form: a frame gives the same bits alone and in a batch)
+                if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 128, 1, 1, 256, false, 2, false, true>(p, s);
+                if (p.tail_cout == 128) return launch_conv_nf<8, 2, 128, 1, 8, 256, false, 2, false, true>(p, s);
+                if (p.tail_cout == 144) return launch_conv_nf<8, 2, 128, 1, 9, 256, false, 2, false, true>(p, s);
+            }
+#endif
             if (p.tail_cout == 16)  return launch_conv_nf<8, 2, 128, 1, 1, 256, false, 2>(p, s);
             if (p.tail_cout == 128) return launch_conv_nf<8, 2, 128, 1, 8, 256, false, 2>(p, s);
             if (p.tail_cout == 144) return launch_conv_nf<8, 2, 128, 1, 9, 256, false, 2>(p, s);
