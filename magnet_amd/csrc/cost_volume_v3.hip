@@ -30,6 +30,7 @@
 // Arithmetic and tolerance contract: as cost_volume_fast.hip (fma-contracted geometry, one v_rcp_f32, padded-map texel
 // coordinates, fp32 view sum); the (mu, sigma) and correlation interpolations use the quad form / difference-form weights,
 // which changes results by fp32 rounding only (homography.py:150-152,155-159).
+#include <stdlib.h>
 #include "cv_runs.hpp"
 
 namespace magnet {
@@ -74,8 +75,12 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
         b = __builtin_amdgcn_readfirstlane(p.magic_tiles ? (int)__umulhi(logical, p.magic_tiles) : (int)logical);        // magic 0 = division by 1
         tile = (int)(logical - (unsigned)b * (unsigned)(p.tiles_x * p.tiles_y));
     }
-    const int y = __builtin_amdgcn_readfirstlane(p.magic_tiles_x ? (int)__umulhi((unsigned)tile, p.magic_tiles_x) : tile);   // raster order: see cost_volume_fast64.hip's launcher
-    const int tx = tile - y * p.tiles_x;
+    int y = __builtin_amdgcn_readfirstlane(p.magic_tiles_x ? (int)__umulhi((unsigned)tile, p.magic_tiles_x) : tile);   // raster order: see cost_volume_fast64.hip's launcher
+    int tx = tile - y * p.tiles_x;
+    if (p.strip_tx == 1) {                                  // column-major tile order: 32-pixel-wide vertical strips (grids wider than 256: the launcher)
+        tx = __builtin_amdgcn_readfirstlane(p.magic_tiles_y ? (int)__umulhi((unsigned)tile, p.magic_tiles_y) : tile);
+        y = tile - tx * p.tiles_y;
+    }
     const int yc = min(y, p.h - 1);
     const int x_base = (tx * 4 + wv) * NPX;
     const size_t hw = (size_t)p.h * p.w;
@@ -349,8 +354,13 @@ static hipError_t launch_v3_v(const CvParams& p0, hipStream_t stream) {
     const uint64_t nt = (uint64_t)p.tiles_x * p.tiles_y;
     p.magic_tiles = nt > 1 ? (uint32_t)((((uint64_t)1 << 32) + nt - 1) / nt) : 0u;
     p.magic_tiles_x = p.tiles_x > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)p.tiles_x - 1) / (uint64_t)p.tiles_x) : 0u;
+    p.magic_tiles_y = p.tiles_y > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)p.tiles_y - 1) / (uint64_t)p.tiles_y) : 0u;
+    // block order: raster rows up to 256-pixel-wide grids; wider ones (C4's 304) walk 32-pixel-wide vertical strips, whose source
+    // footprint per XCD is smaller (profiles/r5/v3_strip.log: C2 0.821 = 0.820 ms, C5 0.882 -> 0.877, C4 0.696 -> 0.682 ms)
+    p.strip_tx = p.w > 256 ? 1 : 0;
     size_t lds = v3_lds_bytes(p, VG);
 #ifdef MAGNET_DEV
+    { static const int strip = getenv("MAGNET_STRIP") ? atoi(getenv("MAGNET_STRIP")) : -1; if (strip >= 0) p.strip_tx = strip; }   // dev: block order A/B
     {   // dev: cap the workgroups per CU (waves per SIMD) by asking for more LDS than the kernel uses
         const int cap = (CV_DEV(p) & 0x300000) == 0x300000 ? 3 : (CV_DEV(p) & 0x200000) ? 4 : (CV_DEV(p) & 0x100000) ? 5 : 0;
         if (cap) { const size_t need = (size_t)160 * 1024 / (cap + 1) + 512; if (lds < need) lds = need; }

@@ -36,8 +36,8 @@ struct CvParams {
     long long      cost_ld;
     uint8_t*       gate_bits;         // optional debug output (B,V,D,h,w)
     int            npx;               // cost_volume_fast64.hip: pixels per wave (set by its launcher)
-    int            strip_tx;          // cost_volume_fast64.hip: > 0 = blocks walk the frame in vertical strips of this many tiles instead of raster order
-    uint32_t       magic_tiles, magic_tiles_x;   // cost_volume_v3.hip: ceil(2^32 / (tiles_x * tiles_y)), ceil(2^32 / tiles_x) (set by its launcher)
+    int            strip_tx;          // cost_volume_fast64.hip / cost_volume_v3.hip: > 0 = blocks walk the frame in vertical strips of this many tiles instead of raster order (v3: 0 or 1)
+    uint32_t       magic_tiles, magic_tiles_x, magic_tiles_y;   // cost_volume_v3.hip: ceil(2^32 / (tiles_x * tiles_y)), ceil(2^32 / tiles_x), ceil(2^32 / tiles_y) (set by its launcher)
     const double*  ray_params;        // optional (B,8) fx, fy, cx, cy, sx, sy, left, top: rays generated in the kernel
     float k[MAGNET_MAX_CANDIDATES];   // (float)k_j, read with wave-uniform indices (scalar loads)
 };
