@@ -440,12 +440,10 @@ static hipError_t launch_fast64_v(const CvParams& p0, hipStream_t stream) {
 
 template <typename FeatT, int CPL, bool FULL, int MINW, int LPU>
 static hipError_t launch_fast64(const CvParams& p, hipStream_t stream) {
-    // views per group: as many as possible (<= 4) without idle slots in the last group
+    // views per group: as many as possible (<= 4) without idle slots in the last group (round 5, C2L, same box: 4 views at 5 waves per
+    // SIMD 1.908 ms; 2 views at 6 waves 1.946; 1 view 1.939; compiled for 8 waves (spills) 2.415: profiles/r5/f64_occupancy.log)
     int vg = p.V >= 4 ? 4 : p.V;
     if (p.V > 4 && p.V % 4 != 0 && (p.V % 3 == 0 || p.V % 4 < p.V % 3)) vg = 3;
-#ifdef MAGNET_DEV
-    { static const int dvg = getenv("MAGNET_F64_VG") ? atoi(getenv("MAGNET_F64_VG")) : 0; if (dvg >= 1 && dvg <= 4) vg = dvg; }   // dev: views per group A/B
-#endif
     switch (vg) {
         case 1: return launch_fast64_v<FeatT, CPL, FULL, MINW, LPU, 1>(p, stream);
         case 2: return launch_fast64_v<FeatT, CPL, FULL, MINW, LPU, 2>(p, stream);
@@ -464,12 +462,6 @@ hipError_t launch_cv_fast64(const CvParams& p, hipStream_t stream, bool* handled
     const int nchunk = (int)(p.F * esz / 16);
     *handled = true;
     if (p.feat_bf16) {
-#ifdef MAGNET_DEV
-        {   static const int dmw = getenv("MAGNET_F64_MINW") ? atoi(getenv("MAGNET_F64_MINW")) : 0;                 // dev: occupancy A/B
-            if (nchunk == 8 && dmw == 6) return launch_fast64<uint16_t, 2, true, 6, 4>(p, stream);
-            if (nchunk == 8 && dmw == 8) return launch_fast64<uint16_t, 2, true, 8, 4>(p, stream);
-        }
-#endif
         if (nchunk == 8)  return launch_fast64<uint16_t, 2, true, 5, 4>(p, stream);       // F = 64: 4 lanes x 32 B per texel
         if (nchunk <= 8)  return launch_fast64<uint16_t, 1, false, 5, 8>(p, stream);
         if (nchunk <= 16) return launch_fast64<uint16_t, 2, false, 5, 8>(p, stream);
