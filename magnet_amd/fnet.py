@@ -132,11 +132,20 @@ class FNetMFMA:
     # every convolution launch appends (start_event, end_event, flops) when set to a list (tools/bench_fnet.py)
     event_sink = None
 
+    # Batches of at least this many images run as TWO half-batches on two HIP streams (round 5).  Every launch of this chain ends in
+    # a burst of output stores that does not depend on K (20 - 35 % of the 32- / 64-channel layers' launches) while the matrix pipes
+    # idle; a second, independent chain out of phase fills those gaps (profiles/r5/fnet_two_streams.log).  Per image the two
+    # halves run the same kernels on the same data, so the result is bit-identical to the one-stream run (tests/test_gpu_fnet.py).
+    split_min_images = 8
+    split_parts = 2
+
     def __init__(self, psm: nn.Module):
         self.psm = psm
         self._packed = None
         self._key = None
         self._bufs = {}
+        self._bufs_sig = None
+        self._streams = {}
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def _params_key(self, device):
@@ -179,12 +188,15 @@ class FNetMFMA:
         return P
 
     # ---- activations -----------------------------------------------------------------------------------------
-    def _buffers(self, dev, N, H, W):
-        key = (str(dev), N, H, W)
+    def _buffers(self, dev, N, H, W, slot=0, sig=None):
+        sig = sig if sig is not None else (str(dev), N, H, W)
+        if self._bufs_sig != sig:                                   # one batch shape at a time: the buffers are large
+            self._bufs.clear()
+            self._bufs_sig = sig
+        key = (str(dev), N, H, W, slot)
         b = self._bufs.get(key)
         if b is not None:
             return b
-        self._bufs.clear()                                          # one shape at a time: the buffers are large
         H2, W2 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         H4, W4 = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
         if H4 < 64 or W4 < 64:
@@ -230,8 +242,52 @@ class FNetMFMA:
         img = img.detach().float().contiguous()
         N, _, H, W = img.shape
         dev = img.device
-        P = self.packed(dev)
-        buf = self._buffers(dev, N, H, W)
+        self.packed(dev)
+        H4, W4 = ((H - 1) // 2 + 1 - 1) // 2 + 1, ((W - 1) // 2 + 1 - 1) // 2 + 1
+        Fd = self.feature_dim
+        sig = (str(dev), N, H, W)
+        if self._bufs_sig != sig:
+            self._bufs.clear()
+            self._bufs_sig = sig
+        # the outputs of the whole batch (the halves of a split run write their slices)
+        if n_ref is None:
+            outs = (torch.empty((N, H4, W4, Fd), dtype=torch.float32, device=dev), None)
+            fe = None
+        else:
+            fe = lib.feat_enum(feat_dtype)
+            dt = lib.feat_torch_dtype(fe)
+            okey = ("out", n_ref, fe)
+            outs = self._bufs.get(okey)
+            if outs is None:
+                outs = self._bufs[okey] = (torch.empty((n_ref, H4, W4, Fd), dtype=dt, device=dev),
+                                           torch.zeros((N - n_ref, H4 + 2, W4 + 2, Fd), dtype=dt, device=dev))   # zero border, never rewritten
+        if N >= self.split_min_images:
+            k = max(2, min(int(self.split_parts), N // 4))
+            cuts = [(N * i + k - 1) // k for i in range(k + 1)]       # contiguous, balanced parts (the first ones take the remainder)
+            parts = [(cuts[i], cuts[i + 1]) for i in range(k)]
+            main = torch.cuda.current_stream(dev)
+            streams = self._streams.setdefault(str(dev), [])
+            while len(streams) < k:
+                streams.append(torch.cuda.Stream(device=dev))
+            ready = torch.cuda.Event(); ready.record(main)
+            for slot, ((lo, hi), st) in enumerate(zip(parts, streams)):
+                st.wait_event(ready)                                 # the images (and the previous consumer of the outputs) are on `main`
+                with torch.cuda.stream(st):
+                    self._run_part(img[lo:hi], slot, sig, n_ref, fe, outs, lo)
+                done = torch.cuda.Event(); done.record(st)
+                main.wait_event(done)
+        else:
+            self._run_part(img, 0, sig, n_ref, fe, outs, 0)
+        if n_ref is None:
+            return outs[0].permute(0, 3, 1, 2).contiguous()
+        return outs
+
+    def _run_part(self, img, slot, sig, n_ref, fe, outs, first):
+        """Images [first, first + len(img)) of the batch through the whole chain on the current stream, with buffer set `slot`."""
+        N, _, H, W = img.shape
+        dev = img.device
+        P = self._packed
+        buf = self._buffers(dev, N, H, W, slot, sig)
         H2, W2, H4, W4, rows_a, rows_b = buf["dims"]
         A, S, Bb, C, cat = buf["A"], buf["S"], buf["B"], buf["C"], buf["cat"]
         wpa, wpb = W2 + 2, W4 + 4
@@ -292,21 +348,15 @@ class FNetMFMA:
         Fd = self.feature_dim
         img_rows = (H4 + 4) * wpb
         if n_ref is None:
-            out = torch.empty((N, H4, W4, Fd), dtype=torch.float32, device=dev)
-            self._conv("lastconv.2", C[0], 128, 128, 1, wpb, rows_b, False, border=bb, repad=1, out_f32=out, out_ld=Fd)
-            return out.permute(0, 3, 1, 2).contiguous()
-        fe = lib.feat_enum(feat_dtype)
-        dt = lib.feat_torch_dtype(fe)
-        okey = ("out", n_ref, fe)
-        outs = buf.get(okey)
-        if outs is None:
-            outs = buf[okey] = (torch.empty((n_ref, H4, W4, Fd), dtype=dt, device=dev),
-                                torch.zeros((N - n_ref, H4 + 2, W4 + 2, Fd), dtype=dt, device=dev))   # zero border, never rewritten
+            self._conv("lastconv.2", C[0], 128, 128, 1, wpb, rows_b, False, border=bb, repad=1, out_f32=outs[0][first:first + N], out_ld=Fd)
+            return
         ref_cl, src_pad = outs
         okw = (lambda t: {"out_bf16": t}) if fe == lib.FEAT_BF16 else (lambda t: {"out_f32": t})
-        self._conv("lastconv.2", C[0], 128, 128, 1, wpb, n_ref * img_rows, False, border=bb, repad=1, out_ld=Fd, **okw(ref_cl))
-        if N > n_ref:
-            tail = (C[0][0][n_ref * img_rows:], C[0][1][n_ref * img_rows:])
-            self._conv("lastconv.2", tail, 128, 128, 1, wpb, (N - n_ref) * img_rows, False, border=bb, repad=2, out_ld=Fd,
-                       **okw(src_pad))
-        return ref_cl, src_pad
+        nr = max(0, min(n_ref - first, N))                          # reference images of this part (they lead the batch)
+        if nr > 0:
+            self._conv("lastconv.2", C[0], 128, 128, 1, wpb, nr * img_rows, False, border=bb, repad=1, out_ld=Fd, **okw(ref_cl[first:first + nr]))
+        if N > nr:
+            tail = (C[0][0][nr * img_rows:], C[0][1][nr * img_rows:])
+            s0 = first + nr - n_ref                                 # first source image of this part, counted among the source images
+            self._conv("lastconv.2", tail, 128, 128, 1, wpb, (N - nr) * img_rows, False, border=bb, repad=2, out_ld=Fd,
+                       **okw(src_pad[s0:s0 + (N - nr)]))

@@ -154,6 +154,26 @@ def test_fnet_matcher_layouts(hip_lib, gpu):
     assert ref_b.dtype == torch.bfloat16 and torch.equal(ref_b, ref_cl.to(torch.bfloat16)) and torch.equal(src_b, src_pad.to(torch.bfloat16))
 
 
+def test_fnet_two_stream_split_is_bit_identical(hip_lib, gpu):
+    """Batches of >= FNetMFMA.split_min_images images run as two half-batches on two HIP streams (the halves' launches fill each other's
+    epilogue gaps).  Per image the same kernels see the same data: the split run must equal the one-stream run bit for bit — NCHW output,
+    and the matcher-layout outputs with the reference / source boundary inside the first half, at the split point and inside the second."""
+    m = seeded_fnet_state(fnet.PSMNet(feature_dim=64), seed=13).eval().to(gpu)
+    run = fnet.FNetMFMA(m)
+    assert run.split_min_images <= 9
+    img = procedural_images(9, 256, 256).to(gpu)                      # odd count: halves of 5 and 4 images
+    one = fnet.FNetMFMA(m); one.split_min_images = 10 ** 9
+    assert torch.equal(run.run(img), one.run(img))
+    for n_ref in (2, 5, 7, 9):
+        for fd in ("fp32", "bf16"):
+            a = [t.clone() for t in run.run(img, n_ref=n_ref, feat_dtype=fd)]
+            b = one.run(img, n_ref=n_ref, feat_dtype=fd)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (n_ref, fd)
+            assert a[1].shape[0] == 9 - n_ref and (a[1].numel() == 0 or (not a[1][:, 0].any() and not a[1][:, :, -1].any()))
+    # a second call re-uses the buffers and streams
+    assert torch.equal(run.run(img), one.run(img))
+
+
 def test_magnet_with_fnet_mfma(hip_lib, gpu):
     """MAGNET.forward with a real PSMNet F-Net: matrix-core F-Net (features handed over in the matcher's layouts) vs the
     torch F-Net + pack path; depth abs_rel difference far below the 1e-4 bar."""

@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--feat-dtype", default="bf16")
     ap.add_argument("--skip-torch", action="store_true")
     ap.add_argument("--profile-layers", action="store_true")
+    ap.add_argument("--no-split", action="store_true", help="one stream for the whole batch (default: two half-batches on two streams)")
+    ap.add_argument("--parts", type=int, default=0, help="dev: number of part-batches / streams (0 = the runner's default)")
     ap.add_argument("--dev-lib", action="store_true", help="bind to libmagnet_hip_dev.so (MAGNET_CONV_VARIANT A/B)")
     a = ap.parse_args()
     if a.dev_lib:
@@ -53,6 +55,10 @@ def main():
     N = 5 * a.frames
     img = torch.randn(N, 3, a.height, a.width, device=dev)
     run = fnet.FNetMFMA(psm)
+    if a.parts:
+        run.split_parts = a.parts
+    if a.no_split or a.profile_layers:                     # (per-layer events of two overlapping chains would not add up to the wall time)
+        run.split_min_images = 10 ** 9
 
     def timed(fn):
         for _ in range(2):
@@ -66,7 +72,7 @@ def main():
     dt = timed(lambda: run.run(img, n_ref=a.frames, feat_dtype=a.feat_dtype))
     rec = {"workload": f"F-Net PSMNet {a.height}x{a.width}, {N} images ({a.frames} ref frames x 5)", "ms_mfma": dt * 1e3,
            "images_per_s_mfma": N / dt, "gflop_per_image": flops_img / 1e9, "tflops_fp32_equiv_mfma": flops_img * N / dt / 1e12,
-           "out": f"matcher layouts, {a.feat_dtype}"}
+           "out": f"matcher layouts, {a.feat_dtype}", "streams": 1 if run.split_min_images > N else run.split_parts}
     if not a.skip_torch:
         fe = lib.feat_enum(a.feat_dtype)
 
