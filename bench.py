@@ -134,6 +134,18 @@ def cpu_baseline(wl, model_cpu, iters, budget_s=10.0):
                                    f"x{cores} threads; 1 call on 1 frame x1 thread"}
 
 
+def _child_env(environ=None) -> dict:
+    """A clean single-process environment for a counter-pass child of this script: under torchrun the parent's rendezvous variables
+    (and TORCHELASTIC_USE_AGENT_STORE, which makes env:// rendezvous a CLIENT of the agent's store) would make the child's own one-rank
+    group wait for a store that does not exist until the pass times out."""
+    environ = os.environ if environ is None else environ
+    env = {k_: v_ for k_, v_ in environ.items()
+           if not (k_.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "GROUP_", "ROLE_")) or
+                   k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))}
+    env["TMPDIR"] = "/tmp"
+    return env
+
+
 def _pmc_passes(passes, child_args, kernel_match, timeout_s=90):
     """One rocprofv3 --kernel-trace --pmc child run of this script per counter group (the guide: counters in their own runs, never
     combined with tracing domains other than the kernel trace).  Returns {counter: mean per dispatch} over the dispatches whose kernel
@@ -151,13 +163,7 @@ def _pmc_passes(passes, child_args, kernel_match, timeout_s=90):
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", tmp, "-o", "p", "--",
                sys.executable, os.path.abspath(__file__), "--no-pmc", "--no-cpu-baseline", "--sustain-s", "0", *child_args]
         try:
-            # a clean single-process environment for the child: under torchrun the parent's rendezvous variables (and
-            # TORCHELASTIC_USE_AGENT_STORE, which makes env:// rendezvous a CLIENT of the agent's store) would make the child's own
-            # one-rank group wait for a store that does not exist until the pass times out
-            env = {k_: v_ for k_, v_ in os.environ.items()
-                   if not (k_.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "GROUP_", "ROLE_")) or
-                           k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK"))}
-            env["TMPDIR"] = "/tmp"
+            env = _child_env()
             # own session: on a timeout the whole group (profiler + the python it started) is stopped, not only the profiler
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:

@@ -116,6 +116,20 @@ def test_roofline_bound_label_follows_the_counters():
     assert bench._bound_label({"valu_busy": 0.5, "ta_busy": 0.9, "wait_frac": 0.2}, None, 1.0).startswith("vector-memory address unit")
 
 
+def test_counter_pass_children_get_a_single_process_environment():
+    """Under `torch.distributed.run --nproc-per-node 1` bench.py's rocprofv3 child runs must not inherit the launcher's rendezvous: with
+    TORCHELASTIC_USE_AGENT_STORE their own one-rank group would wait for the agent's store until the pass timed out (seen in round 5)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_for_test2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    env = bench._child_env({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "LOCAL_WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                            "MASTER_PORT": "29500", "TORCHELASTIC_USE_AGENT_STORE": "True", "TORCHELASTIC_RUN_ID": "x", "GROUP_RANK": "0",
+                            "ROLE_RANK": "0", "PATH": "/usr/bin", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "TMPDIR": "/scratch"})
+    assert env == {"PATH": "/usr/bin", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "TMPDIR": "/tmp"}
+
+
 def test_module_checksum_detects_a_single_changed_weight():
     from magnet_amd import dist as mdist
     net = torch.nn.Linear(7, 5)
