@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     constexpr bool SPLIT = (OPT & 64) != 0;               // the split-bf16 channel-last output form only (cost_hi given): no NCHW staging code, fewer live scalars
     constexpr int NPX = V3_NPX;
     constexpr int IPP = (OPT & 0x1000) && LPU == 4 ? 8 : 64 / (4 * LPU);   // items per correlation pass
+    constexpr bool PX2 = (OPT & 0x2000) != 0 && SPLIT && FULL;   // two pixels per correlation batch (round 5; split output form, F = 64 instances)
     constexpr bool TX = (OPT & 0x1000) != 0 && LPU == 4;   // texel-pair items (8 lanes per pair, 8 pairs per pass); F = 64 bf16 instance only
     constexpr bool QF = LPU == 4 && !(OPT & 128) && !TX;                  // an item's four taps share a 16-lane row: correlations stored in quad form (cv_runs.hpp)
     constexpr int O_IT = TX ? V3T_IT : V3_IT, O_MS = TX ? V3T_MS : V3_MS, O_FIX = TX ? V3T_FIX : V3_FIX;
@@ -180,6 +181,180 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
         const int j = jb * 64 + lane;
         const float kj = p.k[min(j, p.D - 1)];
         const unsigned long long jmask = __builtin_amdgcn_ballot_w64(j < p.D);               // lanes that hold a candidate
+        if constexpr (PX2) {
+            // ---- two pixels per correlation batch ---------------------------------------------------------------------------------
+            // A view group of one pixel opens ~5.5 distinct quads: 1.4 correlation passes of 4 items, i.e. ~2.4 issued (a pass costs
+            // its two wave-loads whatever it holds).  The groups of TWO neighbouring pixels share one item list and one pass sequence
+            // (~11 items: 2.75 passes for both): a third fewer feature wave-loads and dot / reduce instructions, half the LDS round
+            // trips per pixel.  What stays live per (pixel, view) across the batch is 3 registers (bx, by, slot address) and two scalar
+            // masks; the reference vector of an item's pixel comes from the wave's LDS copy per pass instead of from registers.
+            // Arithmetic per candidate and per item is unchanged: results are bit-identical to the one-pixel loop.
+            int pstep = 2;
+            for (int q = 0; q < npix;) {
+                const int pn = min(pstep, npix - q);                                      // pixels of this batch (wave-uniform)
+                float dpx[2], acc2[2] = {0.f, 0.f};
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const uint2 ms = v3_ld_u2(wb + O_MS + (uint32_t)min(q + pp, NPX - 1) * 8u);
+                    dpx[pp] = __builtin_fmaf(__uint_as_float(ms.y), kj, __uint_as_float(ms.x));   // MAGNET.py:155
+                }
+                const uint32_t rf_q = rf_lane + (uint32_t)q * texel_bytes;
+                auto correlate2 = [&](const int n) {
+                    // two passes of loads in flight, ROLLING: as soon as a pass's dot products are done its registers take the loads of the
+                    // pass after next (the one-pixel loop fetches in blocks of NPASS passes and drains between blocks)
+                    const int npass = (n + IPP - 1) / IPP;
+                    uint4 sv[2][CPL];
+                    uint2 ent[2];
+                    auto issue = [&](const int a, const int slot) {
+                        ent[slot] = v3_ld_u2(it_lane + (uint32_t)a * (IPP * 8));                    // past the list: pad entries (dump slot)
+                        const v3_gptr sp = src_b + ((ent[slot].x & ~1u) + lane_src_off);
+#pragma unroll
+                        for (int cc = 0; cc < CPL; ++cc) sv[slot][cc] = v3_gld_u4(sp + cc * CSTR);
+                    };
+                    auto reduce = [&](const int slot) {
+                        const uint32_t ra = rf_q + (ent[slot].x & 1u) * texel_bytes;       // the item's pixel: bit 0 of its entry
+                        float part = 0.f;
+#pragma unroll
+                        for (int cc = 0; cc < CPL; ++cc) part = fdot_chunk(v3_ld_u4(ra + cc * CSTR), sv[slot][cc], part, FeatT());
+                        part = LPU == 8 ? freduce8(part) : v3_reduce4(part);
+                        if (QF) part = v3_quadform16(part);
+                        if (sub == 0) v3_st_f1(ent[slot].y + tap4, part);
+                    };
+                    issue(0, 0);
+                    if (npass > 1) issue(1, 1);
+                    for (int a = 0; a < npass; a += 2) {
+                        reduce(0);
+                        if (a + 2 < npass) issue(a + 2, 0);
+                        if (a + 1 < npass) {
+                            reduce(1);
+                            if (a + 3 < npass) issue(a + 3, 1);
+                        }
+                    }
+                };
+                int gstep = VG;
+                bool redo1 = false;
+                for (int g0 = 0; g0 < nval;) {
+                    const int nact = min(gstep, nval - g0);
+                    float bx[2][VG], by[2][VG];                            // (bx * by is recomputed at the combine: one register less per (pixel, view))
+                    uint32_t keyf[2][VG], raddr[2][VG];
+                    unsigned long long Gb[2][VG], Lb[2][VG];
+                    int n_items = 0;
+                    const uint32_t vta = vtb + (uint32_t)(g0 * 8);
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        if (pp >= pn) {
+#pragma unroll
+                            for (int u = 0; u < VG; ++u) { Gb[pp][u] = 0ull; Lb[pp][u] = 0ull; bx[pp][u] = by[pp][u] = 0.f; keyf[pp][u] = 0u; }
+                            continue;
+                        }
+                        const float d = dpx[pp];
+                        const int x = x_base + q + pp;
+                        float zw[VG], fq[VG];
+                        unsigned long long Wb[VG];
+                        float4 q0[VG], q1[VG];
+                        uint32_t vidx[VG];
+                        const uint32_t pva = pvb + (uint32_t)((g0 * NPX + q + pp) * 32);
+                        auto gate_view = [&](const int u) {
+                            const float mu_w = __builtin_fmaf(fq[u], q0[u].w, __builtin_fmaf(by[pp][u], q0[u].z, __builtin_fmaf(bx[pp][u], q0[u].y, q0[u].x)));   // homography.py:151
+                            const float sg_w = __builtin_fmaf(fq[u], q1[u].w, __builtin_fmaf(by[pp][u], q1[u].z, __builtin_fmaf(bx[pp][u], q1[u].y, q1[u].x)));   // homography.py:152
+                            Gb[pp][u] = __builtin_amdgcn_ballot_w64(__builtin_fabsf(zw[u] - mu_w) < sg_w * kappa) & Wb[u];   // homography.py:157-158
+                            const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)keyf[pp][u], 0x138, 0xf, 0xf, true);
+                            Lb[pp][u] = (__builtin_amdgcn_ballot_w64(keyf[pp][u] != prev) | 1ull | ~(Gb[pp][u] << 1)) & Gb[pp][u];
+                            n_items += v4_popc(Lb[pp][u]);
+                            if (GBITS) {
+                                if (j < p.D && u < nact)
+                                    p.gate_bits[(((size_t)b * p.V + vidx[u]) * p.D + j) * hw + (size_t)y * p.w + x] = (uint8_t)v3_sel_u(Gb[pp][u], 1u, 0u);
+                            }
+                        };
+#pragma unroll
+                        for (int u = 0; u < VG; ++u) {
+                            const float4 pa = v3_ld_f4(pva + u * (NPX * 32)), pb = v3_ld_f4(pva + u * (NPX * 32) + 16);
+                            const uint2 vt = v3_ld_u2(vta + u * 8);
+                            const float Px = __builtin_fmaf(pa.x, d, pb.x);               // homography.py:132
+                            const float Py = __builtin_fmaf(pa.y, d, pb.y);
+                            const float Pz = __builtin_fmaf(pa.z, d, pb.z);
+                            zw[u] = __builtin_fmaf(pa.w, d, pb.w);                        // homography.py:137-138
+                            const float rz = __builtin_amdgcn_rcpf(Pz);                   // homography.py:133
+                            const float ixs = __builtin_fmaf(Px, rz, 0.5f);
+                            const float iys = __builtin_fmaf(Py, rz, 0.5f);
+                            bx[pp][u] = __builtin_amdgcn_fractf(ixs); by[pp][u] = __builtin_amdgcn_fractf(iys);
+                            fq[u] = bx[pp][u] * by[pp][u];
+                            const unsigned long long wx = __builtin_amdgcn_ballot_w64(__float_as_uint(ixs) < xlim);
+                            const unsigned long long wy = __builtin_amdgcn_ballot_w64(__float_as_uint(iys) < ylim);
+                            Wb[u] = (u < nact) ? (wx & wy & jmask) : 0ull;
+                            keyf[pp][u] = __umul24(v3_cvt_u32_sat(iys), (uint32_t)Wp) + v3_cvt_u32_sat(ixs) + vt.x;
+                            const int qo = (int)(keyf[pp][u] << 5);
+                            q0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, qo, 0, 0));
+                            q1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, qo + 16, 0, 0));
+                            if (GBITS) vidx[u] = vt.y;
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (u > 0) { gate_view(u - 1); __builtin_amdgcn_sched_barrier(0); }
+                        }
+                        gate_view(VG - 1);
+                    }
+                    if (n_items == 0) { g0 += nact; continue; }
+                    if (n_items > V3_CAP) {
+                        if (gstep > 1) { gstep = 1; continue; }                           // view by view
+                        redo1 = true; break;                                              // still too many: this pixel alone
+                    }
+                    {
+                        int base = 0;
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                            for (int u = 0; u < VG; ++u) {
+                                const unsigned long long Ls = Lb[pp][u] >> 1;
+                                const int sb = base + (int)(Lb[pp][u] & 1ull) - 1;
+                                const uint32_t cnt = __builtin_amdgcn_mbcnt_hi((uint32_t)(Ls >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Ls, 0u));
+                                raddr[pp][u] = (cnt << 4) + (wb + V3_CT + (uint32_t)(sb * 16));
+                                v3_st2_mask(Lb[pp][u], (cnt << 3) + (wb + V3_IT + (uint32_t)(sb * 8)), __umul24(keyf[pp][u], texel_bytes) | (uint32_t)pp, raddr[pp][u]);
+                                base += v4_popc(Lb[pp][u]);
+                            }
+                    }
+                    v3_st2_mask((1ull << (IPP - 1)) - 1ull, wb + V3_IT + ((uint32_t)n_items + (uint32_t)lane) * 8u, 0u, wb + V3_CT + V3_CAP * 16);
+                    fwave_lds_fence();
+                    correlate2(n_items);
+                    fwave_lds_fence();
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                        for (int u = 0; u < VG; ++u) {
+                            const float4 c4 = v3_ld_f4(raddr[pp][u]);
+                            const float fqc = bx[pp][u] * by[pp][u];
+                            float c;
+                            if (QF) {                                                      // homography.py:150,155
+                                c = __builtin_fmaf(fqc, c4.w, __builtin_fmaf(by[pp][u], c4.z, __builtin_fmaf(bx[pp][u], c4.y, c4.x)));
+                            } else {
+                                const float w10 = bx[pp][u] - fqc, w01 = by[pp][u] - fqc;
+                                const float w00 = (1.0f - bx[pp][u]) - w01;
+                                c = c4.x * w00;
+                                c = __builtin_fmaf(c4.y, w10, c);
+                                c = __builtin_fmaf(c4.z, w01, c);
+                                c = __builtin_fmaf(c4.w, fqc, c);
+                            }
+                            acc2[pp] += v3_sel_f(Gb[pp][u], c, 0.f);                       // homography.py:159,116 (fp32 here)
+                        }
+                    fwave_lds_fence();
+                    g0 += nact;
+                }
+                if (redo1) { pstep = 1; continue; }
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    if (pp < pn) {
+                        const float cval = acc2[pp] * invV;                               // homography.py:118,120
+                        const uint32_t off = (uint32_t)(q + pp) * ld2 + (uint32_t)j * 2u;
+                        if (j < p.D) {
+                            const uint16_t hi = f32_to_bf16_rne(cval);
+                            const uint16_t lo = f32_to_bf16_rne(cval - bf16_to_f32(hi));
+                            *reinterpret_cast<v4_gu16*>(hi_base + off) = hi; *reinterpret_cast<v4_gu16*>(lo_base + off) = lo;
+                        }
+                    }
+                }
+                q += pn;
+                pstep = 2;
+            }
+            continue;
+        }
         for (int q = 0; q < npix; ++q) {
             const int x = x_base + q;
             uint4 rvp[CPL];                                                               // this lane's chunk(s) of the pixel's reference vector
@@ -472,6 +647,15 @@ static hipError_t launch_v3_v(const CvParams& p0, hipStream_t stream) {
         }
     }
 #endif
+    // The split-output form of the F = 64 instances (what MAGNET.forward runs) takes TWO pixels per correlation batch, compiled for 8 waves
+    // per SIMD (63 - 64 registers, no scratch): bit-identical to the one-pixel loop, C2 0.822 -> 0.796 ms (profiles/r5/ablate_px2.log).
+    // dev flag 0x10: the one-pixel loop, same box.
+    if constexpr (FULL && CPL == 2 && VG <= 2) {
+        if (p.cost_hi && !p.gate_bits && !(CV_DEV(p) & 0x10)) {
+            hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, 8, LPU, VG, NP | 64 | 0x2000>), grid, block, lds, stream, p);
+            return hipGetLastError();
+        }
+    }
     if (p.gate_bits) hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MW2, LPU, VG, NP | 1>), grid, block, lds, stream, p);
     else if (p.cost_hi) hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, NP | 64>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MW2, LPU, VG, NP>), grid, block, lds, stream, p);

@@ -45,6 +45,18 @@ if os.environ.get("ABLATE_TX"):                        # round 5: texel-pair ite
     VARIANTS = [("production (auto)", 0), ("same kernel, quad items (rounds 2 - 4)", QI), ("production (auto), again", 0), ("quad items, again", QI)]
     if wl.D > 32 and wl.w <= 512:
         VARIANTS += [("batched-view kernel (fast64), pair items", R2), ("batched-view kernel (fast64), quad items", R2 | QI)]
+if os.environ.get("ABLATE_PX2"):                       # round 5: two pixels per correlation batch in cost_volume_v3.hip (product; dev flag 0x10 = the one-pixel loop; split output only)
+    PX1 = 0x10 << 8
+    VARIANTS = [("production (two pixels per batch, 8 waves)", 0), ("one pixel per batch (rounds 3 - 4)", PX1), ("production, again", 0), ("one pixel per batch, again", PX1)]
+    if split:                                          # bit-identity of the two forms on this workload
+        outs = []
+        for path in (0, PX1):
+            cvx = CostVolumeCW(inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"], inp["is_valid"], inp["cam_intrins"], 5, feat_dtype=fdt, path=path)
+            hi.zero_(); lo.zero_()
+            cvx(ref_gmm=inp["ref_gmms"], k_list=k, out_split=(hi, lo, ld))
+            torch.cuda.synchronize()
+            outs.append((hi.clone(), lo.clone()))
+        print(f"{wl.name}: two-pixel batches bit-identical to the one-pixel loop: {torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])}")
 if os.environ.get("ABLATE_SHORT"):
     VARIANTS = VARIANTS[:2] if os.environ.get("ABLATE_TX") else [VARIANTS[0], VARIANTS[1], VARIANTS[5], VARIANTS[6]]
 for name, path in VARIANTS:
