@@ -297,6 +297,32 @@ def test_fast_split_output_equals_dense(hip_lib, gpu):
         assert torch.all(hi4[:, 1:-1, 1:-1, D:] == poison) and torch.all(hi4[:, 0] == poison) and torch.all(lo4[:, :, -1] == poison)
 
 
+@pytest.mark.parametrize("fdt,w,step", [("bf16", 200, 1.5), ("fp32", 200, 1.5), ("bf16", 43, 0.3)])
+def test_two_pixel_batches_equal_the_one_pixel_loop(hip_lib, gpu, fdt, w, step):
+    """Round 5: the split-output form of the D > 32 kernel (what MAGNET.forward runs) correlates the view groups of TWO neighbouring
+    pixels in one batch; the (B,D,h,w) fp32 form keeps the one-pixel loop.  Same arithmetic per candidate and per item: the split
+    planes must be the bf16 split of the dense volume bit for bit — on long segments too, where a two-pixel batch has more than 64
+    items and falls back to view-by-view, then to the pixel alone (D = 128: two candidate blocks; axis-parallel baselines of 1.5 m with
+    doubled sigma: segments of ~90 texels), and on a ragged row (w = 43: a last segment of 3 pixels, i.e. a batch with one pixel)."""
+    from magnet_amd.convnet import split_bf16
+    from magnet_amd.homography import CostVolumeCW
+    wl = synth.Workload("px2", "scannet", 6, w, V=4, D=128, F=64)
+    inp = synth.make_inputs(wl, B=2, seed=23, round_bf16=(fdt == "bf16"), invalid=[(0, 2)])
+    inp["nghbr_poses"] = _axis_poses(2, 4, step)
+    inp["ref_gmms"][:, 1] *= 2.0
+    d = to_dev(inp, gpu)
+    k = oracle.depth_sampling(3, wl.D)
+    cv = CostVolumeCW(d["ref_feat"], d["nghbr_feat"], d["nghbr_gmms"], d["nghbr_poses"], d["is_valid"], d["cam_intrins"], 5, feat_dtype=fdt, path=4)
+    dense = cv(ref_gmm=d["ref_gmms"], k_list=k)
+    ld = 128 + 256
+    hi = torch.zeros((2 * 8 * (w + 2), ld), dtype=torch.bfloat16, device=gpu); lo = torch.zeros_like(hi)
+    cv(ref_gmm=d["ref_gmms"], k_list=k, out_split=(hi, lo, ld))
+    eh, el = split_bf16(dense.permute(0, 2, 3, 1).contiguous())
+    hi4 = hi.view(2, 8, w + 2, ld); lo4 = lo.view(2, 8, w + 2, ld)
+    assert torch.count_nonzero(dense) > 0.02 * dense.numel()
+    assert torch.equal(hi4[:, 1:-1, 1:-1, :128], eh) and torch.equal(lo4[:, 1:-1, 1:-1, :128], el)
+
+
 def test_fast_batch_independence_at_bench_size(hip_lib, gpu):
     """64 frames per launch (bench.py's step): every frame equals the same frame run alone (no cross-frame state, XCD remap
     bijective), and frames 0 / 63 are within tolerance of the oracle."""
