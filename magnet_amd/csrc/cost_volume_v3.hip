@@ -27,6 +27,11 @@
 // Measured and rejected in round 3: loader lanes that fetch one (mu, sigma) quad per RUN through LDS slots (a
 // quarter of the load instructions, but two more LDS round trips in the dependency chain: 1.11 vs 0.95 ms) and a two-stage
 // software pipeline over groups of two views on top of it (register pressure: 1.38 ms).
+// Round 5 (profiles/r5/NOTES.md): (a) the split-output F = 64 instances correlate the view groups of TWO
+// neighbouring pixels in one batch (PX2 below: ~11 instead of ~5.5 items per pass sequence of 4-item passes, a rolling two-pass load
+// pipeline, reference vectors per pass from LDS; 64 registers = 8 waves; bit-identical; C2 0.823 -> 0.796 ms); (b) grids wider than 256
+// walk 32-pixel-wide vertical strips (C4 0.696 -> 0.682 ms); (c) texel-pair items (TX, see cost_volume_fast64.hip) are built in as a dev
+// variant only: 3.3 % SLOWER here at C2's item counts.
 // Arithmetic and tolerance contract: as cost_volume_fast.hip (fma-contracted geometry, one v_rcp_f32, padded-map texel
 // coordinates, fp32 view sum); the (mu, sigma) and correlation interpolations use the quad form / difference-form weights,
 // which changes results by fp32 rounding only (homography.py:150-152,155-159).
