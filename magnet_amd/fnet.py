@@ -241,6 +241,8 @@ class FNetMFMA:
             raise lib.MagnetError("FNetMFMA folds BatchNorm running statistics: call .eval() on the F-Net first")
         img = img.detach().float().contiguous()
         N, _, H, W = img.shape
+        if n_ref is not None and not (0 <= int(n_ref) <= N):
+            raise lib.MagnetError(f"FNetMFMA: n_ref = {n_ref} outside [0, {N}] (the reference images lead the batch)")
         dev = img.device
         self.packed(dev)
         H4, W4 = ((H - 1) // 2 + 1 - 1) // 2 + 1, ((W - 1) // 2 + 1 - 1) // 2 + 1
