@@ -20,35 +20,36 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
-def _free_port() -> int:
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
 def init_from_env(backend: str | None = None, always: bool = False):
-    """Initialise torch.distributed from the torchrun environment.  Under torchrun the group is created even for one rank;
-    `always=True` (bench.py on a GPU) also creates a ONE-rank group for a plain `python bench.py` (no RANK in the environment,
-    rendezvous on a free local port), so that the N = 1 launch exercises the same rendezvous / RCCL path as N = 8
-    (train_MaGNet.py:197-210 is the reference's pattern).  Without `always` a plain launch stays single-process."""
+    """Initialise torch.distributed from the torchrun environment.  Under torchrun (RANK set) the group is created even for one
+    rank, rendezvous through MASTER_ADDR / MASTER_PORT as the launcher set them (never overwritten here).
+    `always=True` (bench.py on a GPU) also creates a ONE-rank group for a plain `python bench.py` — only when the environment
+    describes a single process (no RANK, WORLD_SIZE absent or 1): the group gets a PRIVATE store (a TCPStore this process owns, bound
+    by the OS to a free port: no probe-then-rebind race between bench processes starting together, nothing read from or written to
+    MASTER_*), so that the N = 1 launch exercises the same RCCL path as N = 8 (train_MaGNet.py:197-210 is the reference's pattern).
+    WORLD_SIZE > 1 without RANK is a broken launcher environment and raises instead of guessing a rendezvous.
+    Without `always` a plain launch stays single-process."""
     rank, world, local = env_world()
-    if (world > 1 or "RANK" in os.environ or always) and not dist.is_initialized():
-        if "RANK" not in os.environ:                       # our own one-rank group: never a client of somebody else's store
-            os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
-            os.environ["MASTER_ADDR"] = "127.0.0.1"
-            os.environ["MASTER_PORT"] = str(_free_port())
+    if dist.is_initialized():
+        return rank, world, local
+    if "RANK" not in os.environ:
+        if world > 1:
+            raise RuntimeError(f"WORLD_SIZE={world} but RANK is not set: launch the ranks with torch.distributed.run "
+                               "(or `python bench.py --gpus N`, which spawns them), or unset WORLD_SIZE")
+        if not always:
+            return rank, world, local
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if "RANK" not in os.environ:                           # our own one-rank group: never a client of somebody else's store
+        kw["store"] = dist.TCPStore("127.0.0.1", 0, 1, is_master=True, wait_for_workers=False)
+    else:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        kw["device_id"] = torch.device("cuda", local)
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 

@@ -263,21 +263,35 @@ class FNetMFMA:
             if outs is None:
                 outs = self._bufs[okey] = (torch.empty((n_ref, H4, W4, Fd), dtype=dt, device=dev),
                                            torch.zeros((N - n_ref, H4 + 2, W4 + 2, Fd), dtype=dt, device=dev))   # zero border, never rewritten
-        if N >= self.split_min_images:
-            k = max(2, min(int(self.split_parts), N // 4))
-            cuts = [(N * i + k - 1) // k for i in range(k + 1)]       # contiguous, balanced parts (the first ones take the remainder)
+        # Two-stream split: k contiguous, balanced, NON-EMPTY parts; split_parts <= 1 (or a batch too small for two parts of >= 4
+        # images) takes the one-stream path
+        k = min(int(self.split_parts), N // 4) if N >= self.split_min_images else 1
+        if k >= 2:
+            cuts = [(N * i + k - 1) // k for i in range(k + 1)]       # the first parts take the remainder; N >= 4k: none is empty
             parts = [(cuts[i], cuts[i + 1]) for i in range(k)]
             main = torch.cuda.current_stream(dev)
             streams = self._streams.setdefault(str(dev), [])
             while len(streams) < k:
                 streams.append(torch.cuda.Stream(device=dev))
             ready = torch.cuda.Event(); ready.record(main)
-            for slot, ((lo, hi), st) in enumerate(zip(parts, streams)):
-                st.wait_event(ready)                                 # the images (and the previous consumer of the outputs) are on `main`
-                with torch.cuda.stream(st):
-                    self._run_part(img[lo:hi], slot, sig, n_ref, fe, outs, lo)
-                done = torch.cuda.Event(); done.record(st)
-                main.wait_event(done)
+            # `img` and `outs` were allocated on `main`; the side streams use them: tell the caching allocator, so that neither block
+            # can be recycled before the side streams are done even if an exception skips the joins below
+            for st in streams[:k]:
+                img.record_stream(st)
+                for t in outs:
+                    if t is not None:
+                        t.record_stream(st)
+            started = []
+            try:
+                for slot, ((lo, hi), st) in enumerate(zip(parts, streams)):
+                    st.wait_event(ready)                             # the images (and the previous consumer of the outputs) are on `main`
+                    started.append(st)
+                    with torch.cuda.stream(st):
+                        self._run_part(img[lo:hi], slot, sig, n_ref, fe, outs, lo)
+            finally:
+                for st in started:                                   # always join: `main` never runs ahead of a side stream's work
+                    done = torch.cuda.Event(); done.record(st)
+                    main.wait_event(done)
         else:
             self._run_part(img, 0, sig, n_ref, fe, outs, 0)
         if n_ref is None:

@@ -112,6 +112,19 @@ class MAGNET(nn.Module):
             # the F-Net) and hands them over — there is no import fallback to a MaGNet checkout.
             raise lib.MagnetError("MAGNET(args, d_net=..., f_net=...): both backbone modules are required "
                                   "(d_net: img -> ((N,2,h,w), (N,256,h,w)); f_net: img -> (N,F,h,w)); see INTEGRATION.md")
+        # Reference behaviour (MAGNET.py:80-92): the frozen backbones are loaded from args.DNET_ckpt / args.FNET_ckpt.  The modules
+        # come from the caller here, but the loading stays this constructor's job: a checkpoint path that is set is loaded into the
+        # passed module (same loader, so a bad path or a key mismatch raises exactly as in the reference); a path that is unset
+        # (None / '') means the caller has initialised the module itself — said once, loudly, because a train_MaGNet.py-style run
+        # would otherwise proceed against randomly initialised frozen backbones.
+        for name, net, key in (("d_net", d_net, "DNET_ckpt"), ("f_net", f_net, "FNET_ckpt")):
+            path = getattr(args, key, None)
+            if path:
+                load_checkpoint(path, net)
+            else:
+                import warnings
+                warnings.warn(f"MAGNET: args.{key} is not set — `{name}` is used as passed (the reference loads it from "
+                              f"args.{key}, models/MAGNET.py:80-92)", stacklevel=2)
         self.d_net = d_net
         self.f_net = f_net
         for net in (self.d_net, self.f_net):

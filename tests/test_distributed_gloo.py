@@ -64,3 +64,38 @@ def test_shard_range_partitions(n, world):
         lo, hi = mdist.shard_range(n, r, world)
         seen += list(range(lo, hi))
     assert seen == list(range(n))
+
+
+def _private_group(q, master_port_before):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    os.environ["MASTER_PORT"] = master_port_before        # somebody else's rendezvous: must be neither used nor overwritten
+    r, w, _ = mdist.init_from_env(backend="gloo", always=True)
+    ok = dist.is_initialized() and dist.get_world_size() == 1 and (r, w) == (0, 1)
+    vals = mdist.gather_floats(3.5)
+    q.put((ok, vals, os.environ.get("MASTER_PORT")))
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_uses_a_private_store_and_leaves_master_env_alone():
+    """`always=True` without RANK: a one-rank group on a store this process owns (OS-assigned port) — several such processes
+    starting together cannot collide, and MASTER_ADDR / MASTER_PORT are not touched."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_private_group, args=(q, "1")) for _ in range(3)]     # port 1: unusable if it were used
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok and vals == [3.5] and port == "1" for ok, vals, port in res), res
+
+
+def test_world_size_without_rank_is_an_error(monkeypatch):
+    """A launcher that exports WORLD_SIZE > 1 but no RANK: every process would otherwise pick its own rendezvous and hang."""
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError, match="RANK is not set"):
+        mdist.init_from_env(backend="gloo", always=True)
+    assert not dist.is_initialized()

@@ -54,6 +54,28 @@ def test_magnet_module_interface():
     assert isinstance(m.g_net, GNET)
 
 
+def test_magnet_loads_backbone_checkpoints_like_the_reference(tmp_path):
+    """models/MAGNET.py:80-92: the constructor loads args.DNET_ckpt / args.FNET_ckpt into the frozen backbones ({'model': sd}
+    or a bare state_dict, 'module.' prefix stripped).  With the modules passed in, a set path is loaded into the passed module;
+    an unset path warns (the module is used as passed); a wrong path raises as the reference's torch.load does."""
+    args = make_args(D=5, iters=1, dpv_h=12, dpv_w=16)
+    src_d, src_f = StubDNet(11), StubFNet(12, fdim=8)
+    torch.save({"model": {"module." + k: v for k, v in src_d.state_dict().items()}}, tmp_path / "d.pt")
+    torch.save(src_f.state_dict(), tmp_path / "f.pt")
+    args.DNET_ckpt, args.FNET_ckpt = str(tmp_path / "d.pt"), str(tmp_path / "f.pt")
+    m = MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2, fdim=8))
+    for got, want in ((m.d_net, src_d), (m.f_net, src_f)):
+        for k, v in want.state_dict().items():
+            assert torch.equal(got.state_dict()[k], v), k
+    assert not any(p.requires_grad for p in list(m.d_net.parameters()) + list(m.f_net.parameters()))
+    args.FNET_ckpt = None
+    with pytest.warns(UserWarning, match="FNET_ckpt is not set"):
+        MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2, fdim=8))
+    args.FNET_ckpt = str(tmp_path / "missing.pt")
+    with pytest.raises(FileNotFoundError):
+        MAGNET(args, d_net=StubDNet(1), f_net=StubFNet(2, fdim=8))
+
+
 def test_magnet_forward_refuses_cpu():
     from magnet_amd import lib
     args = make_args(D=5, iters=1, dpv_h=12, dpv_w=16)
