@@ -192,7 +192,7 @@ def _pmc_passes(passes, child_args, kernel_match, timeout_s=90):
     return vals
 
 
-def live_counters(wl, B, fdt, timeout_s=90):
+def live_counters(wl, B, fdt, timeout_s=90, path=0, dev_lib=False):
     """rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ instruction counters, address-unit busy: separate runs, as
     the guide prescribes) over `bench.py --kernel-only` of the same workload, in child processes.  HBM bytes per launch =
     FETCH_SIZE [KB] x 1024 x 2.0 (gfx950 tallies 128-byte read requests at 64 B: MI355X_MICROARCH.md, HBM) + WRITE_SIZE [KB] x 1024
@@ -201,7 +201,8 @@ def live_counters(wl, B, fdt, timeout_s=90):
     passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
               "SQ": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"],
               "TA": ["TA_BUSY_avr", "GRBM_GUI_ACTIVE"]}
-    vals = _pmc_passes(passes, ["--kernel-only", "--steps", "3", "--warmup", "1", "--workload", wl.name, "--frames", str(B), "--feat-dtype", fdt],
+    vals = _pmc_passes(passes, ["--kernel-only", "--no-group", "--steps", "3", "--warmup", "1", "--workload", wl.name, "--frames", str(B), "--feat-dtype", fdt,
+                                "--path", str(path)] + (["--dev-lib"] if dev_lib else []),
                        lambda k: "cv_" in k and "_kernel" in k, timeout_s)
     traffic = src = sq = binding = None
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
@@ -226,18 +227,35 @@ def live_counters(wl, B, fdt, timeout_s=90):
     return traffic, src, sq, binding
 
 
+def _step_child_args(a, steps, warmup):
+    """The parent's own step configuration for a counter child: every flag that changes what a step executes is forwarded, so the
+    counters describe the configuration of the line they are attached to; what is dropped are the flags that only add measurements
+    (--no-pmc / --no-cpu-baseline / --sustain-s are set by _pmc_passes) and the launcher's (--gpus).  --no-group: the child skips the
+    process group (no RCCL initialisation and no weight broadcast inside the profiler's time budget)."""
+    args = ["--steps", str(steps), "--warmup", str(warmup), "--workload", a.workload, "--no-group",
+            "--path", str(a.path), "--conv-backend", a.conv_backend]
+    if a.frames: args += ["--frames", str(a.frames)]
+    if a.iters: args += ["--iters", str(a.iters)]
+    if a.feat_dtype: args += ["--feat-dtype", a.feat_dtype]
+    for flag, on in (("--no-fuse-tail", a.no_fuse_tail), ("--no-fuse-upsample", a.no_fuse_upsample), ("--graph", a.graph),
+                     ("--overlap", a.overlap), ("--overlap-pack", a.overlap_pack), ("--packed-inputs", a.packed_inputs),
+                     ("--with-fnet", a.with_fnet), ("--dev-lib", a.dev_lib), ("--kernel-only", a.kernel_only), ("--nchw-out", a.nchw_out)):
+        if on: args.append(flag)
+    return args
+
+
 def live_conv_counters(a, timeout_s=120):
     """Matrix-pipe busy share and in-kernel clock of the convolution launches, from one --pmc pass over a short child run of this
-    same step (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs against GRBM_GUI_ACTIVE / 8 XCDs).  None when the pass fails."""
-    vals = _pmc_passes({"MFMA": ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]},
-                       ["--steps", "2", "--warmup", "1", "--workload", a.workload] + (["--frames", str(a.frames)] if a.frames else []),
+    same step — same flags as the parent (_step_child_args) — (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs against GRBM_GUI_ACTIVE / 8 XCDs).
+    None when the pass fails."""
+    vals = _pmc_passes({"MFMA": ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]}, _step_child_args(a, 2, 1),
                        lambda k: "conv_mfma_kernel" in k, timeout_s)
     g = vals.get("GRBM_GUI_ACTIVE")
     if not g or "SQ_VALU_MFMA_BUSY_CYCLES" not in vals:
         return None
     return {"mfma_busy": round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (g / 8), 3),
             "clock_ghz_in_kernel": round(g / 8 / vals["_ns@MFMA"], 3) if vals.get("_ns@MFMA") else None,
-            "source": "live rocprofv3 --pmc pass over this step: mean over all conv_mfma_kernel dispatches"}
+            "source": "live rocprofv3 --pmc pass over this step (same flags, no process group): mean over all conv_mfma_kernel dispatches"}
 
 
 _RESULT_FD = None
@@ -366,7 +384,8 @@ def dry_run(a, rank, world):
                           "weight_broadcast_bytes": bcast_bytes, "fnet_weight_broadcast_bytes": fnet_bytes,
                           "rccl": {"world": world, "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                                    "broadcast_bytes": bcast_bytes + fnet_bytes, "broadcast_verified": bcast_ok},
-                          "cpus_per_rank": [int(v) for v in n_cpus]})
+                          "cpus_per_rank": [int(v) for v in n_cpus],
+                          **({"counters": "N=1 only", "cpu_baseline": "N=1 only"} if world > 1 else {})})
     mdist.barrier()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
@@ -404,6 +423,8 @@ def main():
                     "backbone, not buildable offline).  Reported beside the contract line, never instead of it")
     ap.add_argument("--dev-lib", action="store_true", help="tools/ only: bind to libmagnet_hip_dev.so (python -m magnet_amd.build --dev), "
                     "the build that honours the MAGNET_* variant switches; never a valid result line")
+    ap.add_argument("--no-group", action="store_true", help="no process group for a plain one-process launch (what bench.py's own rocprofv3 "
+                    "counter children use); ignored under a launcher (RANK set)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / distributed self-test without a GPU: gloo backend, "
                     "the step is a no-op (used by tests/test_bench_launcher.py)")
     a = ap.parse_args()
@@ -420,7 +441,7 @@ def main():
     try:
         # always a process group on a GPU — one rank included: RCCL initialisation and the weight broadcast run under the driver's N = 1
         # clock exactly as they will at N = 8 (train_MaGNet.py:197-210)
-        rank, world, local = mdist.init_from_env(backend="gloo" if a.dry_run else None, always=a.dry_run or torch.cuda.is_available())
+        rank, world, local = mdist.init_from_env(backend="gloo" if a.dry_run else None, always=(a.dry_run or torch.cuda.is_available()) and not a.no_group)
     except Exception as e:                                   # a one-rank RCCL group that cannot be created must not take the N = 1 line down
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
             raise
@@ -615,7 +636,7 @@ def main():
     # available or a pass fails — never a stored number)
     traffic, traffic_src, pmc, binding, conv_binding = None, None, None, None, None
     if rank == 0 and world == 1 and not a.no_pmc and not a.kernel_only and a.path == 0:
-        traffic, traffic_src, pmc, binding = live_counters(wl, B, fdt)
+        traffic, traffic_src, pmc, binding = live_counters(wl, B, fdt, path=a.path, dev_lib=a.dev_lib)
         if a.conv_backend == "mfma" and not (a.graph or a.with_fnet):
             conv_binding = live_conv_counters(a)
     alg_bytes = wl.algorithmic_bytes() * B
@@ -686,6 +707,12 @@ def main():
                 res["roofline_conv"].update(conv_binding)
         if model_cpu is not None:
             res["cpu_baseline"] = cpu_baseline(wl, model_cpu, iters)
+        if world > 1:
+            # the contract: counters (roofline.traffic / binding, roofline_conv.mfma_busy) and the CPU baseline are measured on rank 0 of
+            # the N = 1 run only; say so in the N > 1 line instead of leaving the fields silently absent
+            res["roofline"]["traffic_source"] = "N=1 only (live rocprofv3 passes run in the one-GPU launch)"
+            res["counters"] = "N=1 only"
+            res["cpu_baseline"] = "N=1 only"
         _emit_result(res)
     mdist.barrier()
     if torch.distributed.is_available() and torch.distributed.is_initialized():

@@ -276,8 +276,10 @@ typedef struct MagnetConvArgs {
      * (tap, block, output channel).  magnet_pack_mx writes the activation planes; magnet_amd/convnet.py prepares the weights.  The kernel
      * runs hi*hi on the fp16 matrix instruction and lo*hi + hi*lo on the block-scaled fp8 one (x*w to ~1e-5 relative, as the bf16x3 form):
      * 2 matrix-pipe units per product term instead of 3.  NULL / 0 = the bf16x3 format described above.
-     * DOMAIN of this format: |x| <= 65504 (the fp16 plane); magnet_pack_mx clamps larger magnitudes to +-65504 (the bf16x3 format has no
-     * such limit).  `bias` is read with 16-byte loads in every format: 16-byte aligned, as all pointers of this struct. */
+     * DOMAIN of this format: |x| <= 65504 (the fp16 plane); magnet_pack_mx clamps larger magnitudes, +-Inf included, to +-65504 (the
+     * bf16x3 format has no such limit).  NON-FINITE inputs: a NaN is written through to every plane (fp16 NaN, e4m3 NaN; the block
+     * exponents are taken over the finite entries) and the outputs that read it are NaN in BOTH formats; +-Inf propagates as Inf in the
+     * bf16x3 format and is clamped here — the one documented difference between the two formats.  `bias` is read with 16-byte loads in every format: 16-byte aligned, as all pointers of this struct. */
     const void  *in_sc, *w_sc;
     int64_t      sc_rows;
 } MagnetConvArgs;                          /* out_mode 2: one bf16 plane (round-to-nearest-even) at out_hi */

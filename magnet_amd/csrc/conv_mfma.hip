@@ -2274,7 +2274,10 @@ __global__ __launch_bounds__(256) void pack_mx_kernel(const float* __restrict__ 
     for (int c = 0; c < 32; ++c) {
         // domain of the format: |x| <= 65504 (the fp16 plane); larger magnitudes are clamped — an Inf in the fp16 plane would make the
         // residual -Inf and poison the block exponent (the bf16x3 format has no such limit; include/magnet_hip.h states the domain)
-        const float xv = __builtin_amdgcn_fmed3f(tile[pw_idx(blk * 32 + c, q)], -65504.0f, 65504.0f);
+        // NaN is not laundered by the clamp (v_med3_f32 would return a finite bound): it goes through to the fp16 plane and both
+        // e4m3 planes and propagates through the matrix instructions exactly as in the bf16x3 format
+        const float tv = tile[pw_idx(blk * 32 + c, q)];
+        const float xv = tv != tv ? tv : __builtin_amdgcn_fmed3f(tv, -65504.0f, 65504.0f);
         const _Float16 hh = (_Float16)xv;
         hi[c] = (float)hh; lo[c] = xv - hi[c];
         mh = fmaxf(mh, fabsf(hi[c])); ml = fmaxf(ml, fabsf(lo[c]));

@@ -30,8 +30,9 @@
 // Round 5 (profiles/r5/NOTES.md): (a) the split-output F = 64 instances correlate the view groups of TWO
 // neighbouring pixels in one batch (PX2 below: ~11 instead of ~5.5 items per pass sequence of 4-item passes, a rolling two-pass load
 // pipeline, reference vectors per pass from LDS; 64 registers = 8 waves; bit-identical; C2 0.823 -> 0.796 ms); (b) grids wider than 256
-// walk 32-pixel-wide vertical strips (C4 0.696 -> 0.682 ms); (c) texel-pair items (TX, see cost_volume_fast64.hip) are built in as a dev
-// variant only: 3.3 % SLOWER here at C2's item counts.
+// walk 32-pixel-wide vertical strips (C4 0.696 -> 0.682 ms); (c) texel-pair items (cost_volume_fast64.hip's item form) were built into this kernel
+// too and measured 3.3 % SLOWER at C2's item counts (0.851 vs 0.824 ms, profiles/r5/ablate_v3_pair_items.log): removed in round 6 (the code is
+// in the history at 0e28a09); this kernel has quad items only.
 // Arithmetic and tolerance contract: as cost_volume_fast.hip (fma-contracted geometry, one v_rcp_f32, padded-map texel
 // coordinates, fp32 view sum); the (mu, sigma) and correlation interpolations use the quad form / difference-form weights,
 // which changes results by fp32 rounding only (homography.py:150-152,155-159).
@@ -48,11 +49,6 @@ constexpr int V3_CT = 0;                           // [CAP + 1] x 16 B: the 4 ta
 constexpr int V3_IT = 65 * 16;                     // [CAP + 4] x 8 B: open runs {feature byte offset, LDS address of the run's slot}
 constexpr int V3_MS = (V3_IT + 68 * 8 + 15) / 16 * 16;   // [NPX] x 8 B: (mu, sigma) of the wave's reference pixels
 constexpr int V3_FIX = V3_MS + V3_NPX * 8;         // then: view table [Vr] x 8 B, projection table [Vr][NPX] x 32 B, reference vectors, output stage
-// texel-pair items (OPT bit 12; round 5, see cost_volume_fast64.hip's header): slots at V3_CT = 0, entries at V3T_IT
-constexpr int V3T_CAP = 128;                       // pairs of one view group (one view alone never has more: 64 runs x 2)
-constexpr int V3T_IT = (V3T_CAP + 8) * 8;          // [CAP + 8 dump] x 8 B slots {c0, c1 - c0} come first; here: [CAP + 8] x 8 B entries {byte offset of texel 0, of texel 1}
-constexpr int V3T_MS = 2 * V3T_IT;
-constexpr int V3T_FIX = V3T_MS + V3_NPX * 8;
 
 // CPL / FULL / LPU: VALU correlation units of LPU lanes x CPL 16-byte chunks (as cv_fast_kernel); VG = views per group;
 // OPT bit 0: write the gate bits (debug / parity tests); bit 1 (dev builds): no dot products; bit 6: split output form only;
@@ -63,11 +59,10 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     constexpr bool NO_CORR = (OPT & 2) != 0;              // dev: no feature loads / dot products
     constexpr bool SPLIT = (OPT & 64) != 0;               // the split-bf16 channel-last output form only (cost_hi given): no NCHW staging code, fewer live scalars
     constexpr int NPX = V3_NPX;
-    constexpr int IPP = (OPT & 0x1000) && LPU == 4 ? 8 : 64 / (4 * LPU);   // items per correlation pass
+    constexpr int IPP = 64 / (4 * LPU);                   // items per correlation pass
     constexpr bool PX2 = (OPT & 0x2000) != 0 && SPLIT && FULL;   // two pixels per correlation batch (round 5; split output form, F = 64 instances)
-    constexpr bool TX = (OPT & 0x1000) != 0 && LPU == 4;   // texel-pair items (8 lanes per pair, 8 pairs per pass); F = 64 bf16 instance only
-    constexpr bool QF = LPU == 4 && !(OPT & 128) && !TX;                  // an item's four taps share a 16-lane row: correlations stored in quad form (cv_runs.hpp)
-    constexpr int O_IT = TX ? V3T_IT : V3_IT, O_MS = TX ? V3T_MS : V3_MS, O_FIX = TX ? V3T_FIX : V3_FIX;
+    constexpr bool QF = LPU == 4 && !(OPT & 128);                         // an item's four taps share a 16-lane row: correlations stored in quad form (cv_runs.hpp)
+    constexpr int O_IT = V3_IT, O_MS = V3_MS, O_FIX = V3_FIX;
     constexpr int NPASS = ((OPT >> 8) & 15) ? ((OPT >> 8) & 15) : V3_NPASS_DEFAULT;   // passes fetched together
     constexpr int CSTR = LPU * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -114,10 +109,9 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     // ---- wave-private LDS ----
     const int vt_bytes = Vr * 8, pv_bytes = Vr * NPX * 32, rf_bytes = NPX * (int)texel_bytes;
     const int out_bytes = (SPLIT || p.cost_hi) ? 0 : NPX * 64 * 4;
-    const int md_bytes = TX ? Vr * NPX * 4 : 0;                                             // TX: travel mode per (view, pixel)
-    const int wave_bytes = O_FIX + (vt_bytes + 15) / 16 * 16 + pv_bytes + rf_bytes + out_bytes + md_bytes;
+    const int wave_bytes = O_FIX + (vt_bytes + 15) / 16 * 16 + pv_bytes + rf_bytes + out_bytes;
     const uint32_t wb = (uint32_t)(uintptr_t)(v3_lds_u8*)smem + (uint32_t)(wv * wave_bytes);
-    const uint32_t vtb = wb + O_FIX, pvb = vtb + (vt_bytes + 15) / 16 * 16, rfb = pvb + pv_bytes, outb = rfb + rf_bytes, mdb = outb + out_bytes;
+    const uint32_t vtb = wb + O_FIX, pvb = vtb + (vt_bytes + 15) / 16 * 16, rfb = pvb + pv_bytes, outb = rfb + rf_bytes;
 
     // ---- per (compact view c, pixel q): depth-linear projection terms; per compact view: {texel offset of the view, view index} ----
     for (int e = lane; e < NPX * Vr; e += 64) {
@@ -136,7 +130,6 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
         v3_st_f4(pvb + e * 32, make_float4(pv.rpx, pv.rpy, pv.rpz, pv.rcz));
         v3_st_f4(pvb + e * 32 + 16, make_float4(pv.kt0, pv.kt1, pv.kt2, pv.tz));
         if (q == 0) v3_st_u2(vtb + (e / NPX) * 8, make_uint2((uint32_t)v * vstride, (uint32_t)v));
-        if (TX) v3_st_u1(mdb + e * 4, travel_mode(pv));
     }
     // ---- reference vectors and (mu, sigma) of the wave's pixels (contiguous in their rows): staged once ----
     {
@@ -156,8 +149,8 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     fwave_lds_fence();
 
     const uint32_t xlim = __float_as_uint((float)(p.w + 1)), ylim = __float_as_uint((float)(p.h + 1));   // see cost_volume_fast.hip
-    const int sub = lane & (LPU - 1), tap = TX ? ((lane >> 2) & 1) : ((lane / LPU) & 3), upair = TX ? (lane >> 3) : lane / (4 * LPU);   // correlation roles
-    const uint32_t lane_src_off = (TX ? 0u : (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes) + (uint32_t)sub * 16u;
+    const int sub = lane & (LPU - 1), tap = (lane / LPU) & 3, upair = lane / (4 * LPU);   // correlation roles
+    const uint32_t lane_src_off = (uint32_t)((tap & 1) + (tap >> 1) * Wp) * texel_bytes + (uint32_t)sub * 16u;
     const uint32_t tap4 = (uint32_t)tap * 4u;
     const float invV = 1.0f / (float)p.V;
     // frame bases pinned into SGPRs and typed as GLOBAL pointers: base + zero-extended 32-bit lane offset then selects the
@@ -177,8 +170,7 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     const uint32_t ld2 = (uint32_t)p.cost_ld * 2u;
 
     const int npix = min(NPX, p.w - x_base);                                                // pixels of the segment inside the row (may be <= 0)
-    const uint32_t it_lane = wb + O_IT + (uint32_t)upair * 8u + (TX ? (uint32_t)tap * 4u : 0u);   // correlation unit -> its item entry of pass 0 (TX: this texel's offset inside the entry)
-    const uint32_t ct_lane = wb + V3_CT + (uint32_t)upair * 8u + (uint32_t)tap * 4u;         // TX: where the unit's correlation goes (slot = item index)
+    const uint32_t it_lane = wb + O_IT + (uint32_t)upair * 8u;                              // correlation unit -> its item entry of pass 0
     const uint32_t row_bytes = (uint32_t)Wp * texel_bytes;
     const uint32_t rf_lane = rfb + (uint32_t)sub * 16u;
 
@@ -375,35 +367,6 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
 
             // (item, tap) dot products of the n open runs listed in the item table -> the runs' slots
             auto correlate = [&](const int n) {
-                if constexpr (TX) {
-                    // pairs: 8 lanes per item (4 lanes x 32 B per texel, 2 texels), 8 items per pass; the unit's correlation goes to slot
-                    // (item index) as {c0, c1 - c0}: the second texel's lanes subtract the first texel's sum in the lanes (bank-masked DPP)
-                    for (int ps = 0; ps < n; ps += IPP * NPASS) {
-                        uint4 sv[NPASS][CPL];
-                        uint32_t off[NPASS];
-                        const uint32_t ita = it_lane + (uint32_t)ps * 8u;
-#pragma unroll
-                        for (int a = 0; a < NPASS; ++a) off[a] = v3_ld_u1(ita + a * (IPP * 8));                // past the list: pad entries
-#pragma unroll
-                        for (int a = 0; a < NPASS; ++a) {
-                            if (a > 0 && ps + IPP * a >= n) break;                        // wave-uniform: this pass holds no item
-                            const v3_gptr sp = src_b + (off[a] + lane_src_off);
-#pragma unroll
-                            for (int cc = 0; cc < CPL; ++cc) sv[a][cc] = v3_gld_u4(sp + cc * CSTR);
-                        }
-#pragma unroll
-                        for (int a = 0; a < NPASS; ++a) {
-                            if (a > 0 && ps + IPP * a >= n) break;
-                            float part = 0.f;
-#pragma unroll
-                            for (int cc = 0; cc < CPL; ++cc) part = fdot_chunk(rvp[cc], sv[a][cc], part, FeatT());
-                            part = v3_reduce4(part);
-                            asm volatile("s_nop 1\n\tv_subrev_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(part));   // banks 1, 3 (second texels): c1 -= c0
-                            if (sub == 0) v3_st_f1(ct_lane + (uint32_t)(ps + IPP * a) * 8u, part);            // units past the list write dump slots
-                        }
-                    }
-                    return;
-                }
                 for (int ps = 0; ps < n; ps += IPP * NPASS) {
                     uint4 sv[NPASS][CPL];
                     uint2 ent[NPASS];
@@ -436,8 +399,7 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
                 const int nact = min(gstep, nval - g0);
                 float bx[VG], by[VG], fxy[VG], zw[VG];
                 uint32_t keyf[VG], raddr[VG];
-                unsigned long long Wb[VG], Gb[VG], Lb[VG], Sb[VG];
-                uint32_t md[VG];                                                          // TX: travel mode of (pixel, view) (cv_fast_common.hpp: travel_mode), wave-uniform
+                unsigned long long Wb[VG], Gb[VG], Lb[VG];
                 float4 q0[VG], q1[VG];
                 uint32_t vidx[VG];
                 const uint32_t pva = pvb + (uint32_t)((g0 * NPX + q) * 32);
@@ -453,13 +415,6 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
                     // runs of equal quads among the OPEN lanes: leader = open and (lane 0, or another quad than the previous lane, or the previous lane closed)
                     const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)keyf[u], 0x138, 0xf, 0xf, true);   // wave_shr:1, lane 0 <- 0
                     Lb[u] = (__builtin_amdgcn_ballot_w64(keyf[u] != prev) | 1ull | ~(Gb[u] << 1)) & Gb[u];
-                    if constexpr (TX) {
-                        // a leader whose quad is the previous (open) lane's quad moved one step along the direction of travel re-uses that
-                        // run's second pair: one more compare on the DPP value above
-                        const uint32_t step = ((md[u] & 1u) ? (uint32_t)Wp : 1u) * ((md[u] & 2u) ? 0xffffffffu : 1u);
-                        Sb[u] = __builtin_amdgcn_ballot_w64(prev + step == keyf[u]) & Lb[u] & (Gb[u] << 1);
-                        n_items += 2 * v4_popc(Lb[u]) - v4_popc(Sb[u]);
-                    } else
                     n_items += __popcll(Lb[u]);
                     if (GBITS) {
                         if (j < p.D && u < nact)
@@ -470,7 +425,6 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
                 for (int u = 0; u < VG; ++u) {
                     const float4 pa = v3_ld_f4(pva + u * (NPX * 32)), pb = v3_ld_f4(pva + u * (NPX * 32) + 16);
                     const uint2 vt = v3_ld_u2(vta + u * 8);
-                    if constexpr (TX) md[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v3_ld_u1(mdb + (uint32_t)(((g0 + u) * NPX + q) * 4)));
                     const float Px = __builtin_fmaf(pa.x, d, pb.x);                       // homography.py:132
                     const float Py = __builtin_fmaf(pa.y, d, pb.y);
                     const float Pz = __builtin_fmaf(pa.z, d, pb.z);
@@ -495,34 +449,8 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
                 }
                 gate_view(VG - 1);
                 if (n_items == 0) { g0 += nact; continue; }                               // wave-uniform: nothing open in this group
-                if (n_items > (TX ? V3T_CAP : V3_CAP)) { gstep = 1; continue; }           // (only with nact > 1) redo view by view
-                if constexpr (TX) {
-                    // pairs of a view are numbered along increasing x (y) whatever its direction of travel (a view travelling down is numbered
-                    // backwards), so that a quad is always (pair s, pair s + 1) in coordinate order and the combine needs no direction
-                    int base = 0;
-#pragma unroll
-                    for (int u = 0; u < VG; ++u) {
-                        const unsigned long long Nb = Lb[u] & ~Sb[u];                     // leaders that emit two pairs
-                        const unsigned long long Ls = Lb[u] >> 1, Ns = Nb >> 1;
-                        // first pair of the lane's quad in travel order = (leaders + two-pair leaders at or below the lane) - 2
-                        const uint32_t tv = __builtin_amdgcn_mbcnt_hi((uint32_t)(Ns >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Ns,
-                                            __builtin_amdgcn_mbcnt_hi((uint32_t)(Ls >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Ls, 0u))));
-                        const int cnt_u = 2 * v4_popc(Lb[u]) - v4_popc(Sb[u]);
-                        const int c0 = (int)(Lb[u] & 1ull) + (int)(Nb & 1ull) - 2;
-                        const bool neg = (md[u] & 2u) != 0, rowm = (md[u] & 1u) != 0;
-                        // slot index = base + t (up) or base + cnt - 2 - t (down), t = tv + c0
-                        if (neg) raddr[u] = (wb + V3_CT + (uint32_t)((base + cnt_u - 2 - c0) * 8)) - (tv << 3);
-                        else     raddr[u] = (tv << 3) + (wb + V3_CT + (uint32_t)((base + c0) * 8));
-                        const uint32_t oJ = rowm ? row_bytes : texel_bytes, oM = rowm ? texel_bytes : row_bytes;
-                        const uint32_t o0 = __umul24(keyf[u], texel_bytes), o1 = o0 + oJ;
-                        const uint32_t ia = raddr[u] + (uint32_t)V3T_IT;                     // the slot's entry
-                        // a sharing leader's re-used pair: its first (coordinate order) when travelling up, its second when travelling down
-                        v3_st2_mask(neg ? Lb[u] : Nb, ia, o0, o0 + oM);
-                        v3_st2_mask(neg ? Nb : Lb[u], ia + 8u, o1, o1 + oM);
-                        base += cnt_u;
-                    }
-                    v3_st2_mask((1ull << (IPP - 1)) - 1ull, wb + O_IT + ((uint32_t)n_items + (uint32_t)lane) * 8u, 0u, 0u);   // pad entries: texel 0
-                } else {
+                if (n_items > V3_CAP) { gstep = 1; continue; }                                     // (only with nact > 1) redo view by view
+                {
                     int base = 0;
 #pragma unroll
                     for (int u = 0; u < VG; ++u) {
@@ -535,7 +463,7 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
                         base += __popcll(Lb[u]);
                     }
                 }
-                if (IPP > 1 && !TX)
+                if (IPP > 1)
                     v3_st2_mask((1ull << (IPP - 1)) - 1ull, wb + V3_IT + ((uint32_t)n_items + (uint32_t)lane) * 8u, 0u, wb + V3_CT + V3_CAP * 16);
                 fwave_lds_fence();
                 if (!NO_CORR) correlate(n_items);
@@ -543,17 +471,6 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
 #pragma unroll
                 for (int u = 0; u < VG; ++u) {
                     float c;
-                    if constexpr (TX) {
-                        // pairs s, s + 1 = {c0, c1 - c0} at the lower / upper coordinate of the travel axis: lerp across, then along
-                        const uint2 pa = v3_ld_u2(raddr[u]), pb = v3_ld_u2(raddr[u] + 8u);
-                        const bool rowm = (md[u] & 1u) != 0;                              // wave-uniform
-                        const float fmin = rowm ? bx[u] : by[u], fmaj = rowm ? by[u] : bx[u];
-                        const float t = __builtin_fmaf(fmin, __uint_as_float(pa.y), __uint_as_float(pa.x));
-                        const float l = __builtin_fmaf(fmin, __uint_as_float(pb.y), __uint_as_float(pb.x));
-                        c = __builtin_fmaf(fmaj, l - t, t);                               // homography.py:150,155
-                        acc += v3_sel_f(Gb[u], c, 0.f);
-                        continue;
-                    }
                     const float4 c4 = v3_ld_f4(raddr[u]);
                     if (QF) {                                                              // homography.py:150,155 (grid_sample's bilinear weights, factored)
                         c = __builtin_fmaf(fxy[u], c4.w, __builtin_fmaf(by[u], c4.z, __builtin_fmaf(bx[u], c4.y, c4.x)));
@@ -603,10 +520,10 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     }
 }
 
-static size_t v3_lds_bytes(const CvParams& p, int vg, bool tx = false) {
+static size_t v3_lds_bytes(const CvParams& p, int vg) {
     const size_t esz = p.feat_bf16 ? 2 : 4;
     const int Vr = (p.V + vg - 1) / vg * vg;
-    return (size_t)4 * ((tx ? V3T_FIX + Vr * V3_NPX * 4 : V3_FIX) + (Vr * 8 + 15) / 16 * 16 + Vr * V3_NPX * 32 + V3_NPX * p.F * esz + (p.cost_hi ? 0 : V3_NPX * 64 * 4));
+    return (size_t)4 * (V3_FIX + (Vr * 8 + 15) / 16 * 16 + Vr * V3_NPX * 32 + V3_NPX * p.F * esz + (p.cost_hi ? 0 : V3_NPX * 64 * 4));
 }
 
 template <typename FeatT, int CPL, bool FULL, int MINW, int LPU, int VG>
@@ -640,17 +557,6 @@ static hipError_t launch_v3_v(const CvParams& p0, hipStream_t stream) {
     if (p.cost_hi && (CV_DEV(p) & 0x4000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x200>), grid, block, lds, stream, p); return hipGetLastError(); }
     if (p.cost_hi && (CV_DEV(p) & 0x40000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x300>), grid, block, lds, stream, p); return hipGetLastError(); }
     if (p.cost_hi && (CV_DEV(p) & 0x80000)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, 64 | 0x400>), grid, block, lds, stream, p); return hipGetLastError(); }
-#endif
-#ifdef MAGNET_DEV
-    if constexpr (LPU == 4) {
-        if (CV_DEV(p) & 0x400) {                                                           // dev: texel-pair items (round 5), same-box A/B
-            const size_t lt = v3_lds_bytes(p, VG, true);
-            if (p.gate_bits) hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MW2, LPU, VG, NP | 1 | 0x1000>), grid, block, lt, stream, p);
-            else if (p.cost_hi) hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MINW, LPU, VG, NP | 64 | 0x1000>), grid, block, lt, stream, p);
-            else hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, MW2, LPU, VG, NP | 0x1000>), grid, block, lt, stream, p);
-            return hipGetLastError();
-        }
-    }
 #endif
     // The split-output form of the F = 64 instances (what MAGNET.forward runs) takes TWO pixels per correlation batch, compiled for 8 waves
     // per SIMD (63 - 64 registers, no scratch): bit-identical to the one-pixel loop, C2 0.822 -> 0.796 ms (profiles/r5/ablate_px2.log).

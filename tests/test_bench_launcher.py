@@ -24,6 +24,7 @@ def test_bench_spawns_two_ranks_dry_run():
     d = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--frames", "5"])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert d["config"]["frames_per_step_all_ranks"] == 10                 # 5 frames per rank, every frame owned once
+    assert d["counters"] == "N=1 only" and d["cpu_baseline"] == "N=1 only"   # the N > 1 line says where those fields are measured
     assert d["weight_broadcast_bytes"] == (9 * (256 + 64) * 128 + 128 + 2 * (128 * 128 + 128) + 2 * 128 + 2) * 4   # G-Net at D=64
 
 

@@ -273,6 +273,30 @@ def test_pack_mx_equals_the_torch_restatement(hip_lib, gpu):
     assert f16.view(B, h + 2, w + 2, C)[:, 0].abs().sum().item() == 0 and sc.view(C // 32, B, h + 2, w + 2)[:, :, :, 0].abs().sum().item() == 0
 
 
+def test_pack_mx_non_finite_inputs(hip_lib, gpu):
+    """include/magnet_hip.h (v302 domain note): a NaN is written through to the fp16 plane and to both e4m3 planes — it is not turned
+    into a finite bound by the clamp — while the block exponents come from the block's finite entries; +-Inf and |x| > 65504 clamp to
+    +-65504; every other (row, block) is untouched by a neighbour's NaN."""
+    from magnet_amd.convnet import split_mx
+    g = torch.Generator().manual_seed(5)
+    B, C, h, w = 1, 64, 6, 8
+    x = torch.randn(B, C, h, w, generator=g)
+    x[0, 3, 2, 4] = float("nan")
+    x[0, 40, 1, 1] = float("inf"); x[0, 41, 1, 1] = -1.0e9
+    f16, qr, sc, rows = _pack_mx_planes(x, gpu)
+    f = f16.view(B, h + 2, w + 2, C)[:, 1:-1, 1:-1].cpu()
+    q8 = qr.view(B, h + 2, w + 2, C)[:, 1:-1, 1:-1].cpu().contiguous().view(torch.uint8).view(B, h, w, C // 32, 64)
+    assert torch.isnan(f[0, 2, 4, 3]) and int(torch.isnan(f).sum()) == 1
+    assert (int(q8[0, 2, 4, 0, 3]) & 0x7f) == 0x7f and (int(q8[0, 2, 4, 0, 32 + 3]) & 0x7f) == 0x7f        # e4m3 NaN in the hi and lo bytes
+    assert f[0, 1, 1, 40].item() == 65504.0 and f[0, 1, 1, 41].item() == -65504.0
+    # everything that is not in the NaN's own (pixel, block) equals the finite restatement of the clamped tensor
+    xc = torch.nan_to_num(x, nan=0.0).clamp(-65504.0, 65504.0).permute(0, 2, 3, 1).contiguous()
+    hi, q, s_ = split_mx(xc)
+    keep = torch.ones(B, h, w, C, dtype=torch.bool); keep[0, 2, 4, :32] = False
+    assert torch.equal(f[keep], hi[keep])
+    assert torch.equal(qr.view(B, h + 2, w + 2, C)[:, 1:-1, 1:-1].cpu()[keep], q[keep])
+
+
 @pytest.mark.parametrize("cin,cout", [(320, 2), (256, 144)])
 def test_conv_stack_mx_format_matches_fp32(hip_lib, gpu, cin, cout):
     """The 2-unit operand format (fp16 main term + block-scaled e4m3 correction terms) on the chip-filling shape, against torch fp32:
