@@ -53,6 +53,14 @@ constexpr int V3_FIX = V3_MS + V3_NPX * 8;         // then: view table [Vr] x 8 
 // CPL / FULL / LPU: VALU correlation units of LPU lanes x CPL 16-byte chunks (as cv_fast_kernel); VG = views per group;
 // OPT bit 0: write the gate bits (debug / parity tests); bit 1 (dev builds): no dot products; bit 6: split output form only;
 // bits 8..11: correlation passes whose loads are in flight together
+// dev A/B (HALFQ): q0 holds 8 fp16 {mu quad form, sigma quad form}; widen to the two fp32 quads
+__device__ __forceinline__ void v3_unpack_quad16(float4& q0, float4& q1) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+    const h2_t a = __builtin_bit_cast(h2_t, q0.x), b = __builtin_bit_cast(h2_t, q0.y), c = __builtin_bit_cast(h2_t, q0.z), d = __builtin_bit_cast(h2_t, q0.w);
+    q0 = make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+    q1 = make_float4((float)c[0], (float)c[1], (float)d[0], (float)d[1]);
+}
+
 template <typename FeatT, int CPL, bool FULL, int MINW, int LPU, int VG, int OPT>
 __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     constexpr bool GBITS = (OPT & 1) != 0;
@@ -60,6 +68,9 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     constexpr bool SPLIT = (OPT & 64) != 0;               // the split-bf16 channel-last output form only (cost_hi given): no NCHW staging code, fewer live scalars
     constexpr int NPX = V3_NPX;
     constexpr int IPP = 64 / (4 * LPU);                   // items per correlation pass
+    constexpr int HALFQ = (OPT >> 14) & 3;                // dev A/B (round 6, tools/ablate.py ABLATE_HALFQ): the quad-form (mu, sigma) entry as 8 fp16 = ONE 16-byte
+                                                          // load per candidate from a 16-byte-stride map (the tool converts the map); gates differ from the fp32 map's
+                                                          // at the 1e-3 level (outside the contract), the amount of work does not: what the map's bytes cost
     constexpr bool PX2 = (OPT & 0x2000) != 0 && SPLIT && FULL;   // two pixels per correlation batch (round 5; split output form, F = 64 instances)
     constexpr bool QF = LPU == 4 && !(OPT & 128);                         // an item's four taps share a 16-lane row: correlations stored in quad form (cv_runs.hpp)
     constexpr int O_IT = V3_IT, O_MS = V3_MS, O_FIX = V3_FIX;
@@ -161,8 +172,8 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
     const v3_gptr src_b = uniform_base(reinterpret_cast<const unsigned char*>(p.src_feat) + (size_t)b * map_texels * texel_bytes);
     // quad-form (mu, sigma) map of frame b over all views, as a buffer: the hardware bounds check replaces the clamp of the quad key
     const __amdgpu_buffer_rsrc_t rsrc_q = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)v4_uniform_ptr(reinterpret_cast<const unsigned char*>(p.src_gmq) + (size_t)b * map_texels * 32), 0,
-        (int)(((uint32_t)(p.V - 1) * vstride + map_texels) * 32u), 0x00020000);
+        (void*)v4_uniform_ptr(reinterpret_cast<const unsigned char*>(p.src_gmq) + (size_t)b * map_texels * (HALFQ ? 16 : 32)), 0,
+        (int)(((uint32_t)(p.V - 1) * vstride + map_texels) * (HALFQ ? 16u : 32u)), 0x00020000);
     const float kappa = p.kappa;
     // split output: bases of the wave's first pixel pinned into SGPRs, per pixel a 32-bit byte offset (round 4; was 64-bit per-lane math)
     v4_gu8* const hi_base = (SPLIT || p.cost_hi) ? v4_uniform_gptr(p.cost_hi + (((size_t)b * Hp + (y + 1)) * Wp + (x_base + 1)) * (size_t)p.cost_ld) : nullptr;
@@ -280,9 +291,10 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
                             const unsigned long long wy = __builtin_amdgcn_ballot_w64(__float_as_uint(iys) < ylim);
                             Wb[u] = (u < nact) ? (wx & wy & jmask) : 0ull;
                             keyf[pp][u] = __umul24(v3_cvt_u32_sat(iys), (uint32_t)Wp) + v3_cvt_u32_sat(ixs) + vt.x;
-                            const int qo = (int)(keyf[pp][u] << 5);
+                            const int qo = (int)(keyf[pp][u] << (HALFQ ? 4 : 5));
                             q0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, qo, 0, 0));
-                            q1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, qo + 16, 0, 0));
+                            if constexpr (HALFQ != 0) v3_unpack_quad16(q0[u], q1[u]);
+                            else q1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, qo + 16, 0, 0));
                             if (GBITS) vidx[u] = vt.y;
                             __builtin_amdgcn_sched_barrier(0);
                             if (u > 0) { gate_view(u - 1); __builtin_amdgcn_sched_barrier(0); }
@@ -440,9 +452,10 @@ __global__ __launch_bounds__(256, MINW) void cv_v3_kernel(const CvParams p) {
                     // quad index relative to (frame b, view 0): truncation = floor inside the window (ixs, iys >= 0); garbage outside it
                     keyf[u] = __umul24(v3_cvt_u32_sat(iys), (uint32_t)Wp) + v3_cvt_u32_sat(ixs) + vt.x;
                     // bounds-checked buffer loads (round 4): the key of a lane outside the window is garbage and reads as zero; was min + global load
-                    const int qo = (int)(keyf[u] << 5);
+                    const int qo = (int)(keyf[u] << (HALFQ ? 4 : 5));
                     q0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, qo, 0, 0));
-                    q1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, qo + 16, 0, 0));
+                    if constexpr (HALFQ != 0) v3_unpack_quad16(q0[u], q1[u]);
+                    else q1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, qo + 16, 0, 0));
                     if (GBITS) vidx[u] = vt.y;
                     __builtin_amdgcn_sched_barrier(0);
                     if (u > 0) { gate_view(u - 1); __builtin_amdgcn_sched_barrier(0); }
@@ -561,6 +574,11 @@ static hipError_t launch_v3_v(const CvParams& p0, hipStream_t stream) {
     // The split-output form of the F = 64 instances (what MAGNET.forward runs) takes TWO pixels per correlation batch, compiled for 8 waves
     // per SIMD (63 - 64 registers, no scratch): bit-identical to the one-pixel loop, C2 0.822 -> 0.796 ms (profiles/r5/ablate_px2.log).
     // dev flag 0x10: the one-pixel loop, same box.
+#ifdef MAGNET_DEV
+    if constexpr (FULL && CPL == 2 && VG <= 2) {       // dev A/B 0x80: the product instance reading an fp16 quad-form map (16 B per candidate, 16-byte stride; see HALFQ)
+        if (p.cost_hi && !p.gate_bits && (CV_DEV(p) & 0x80)) { hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, 8, LPU, VG, NP | 64 | 0x2000 | 0x4000>), grid, block, lds, stream, p); return hipGetLastError(); }
+    }
+#endif
     if constexpr (FULL && CPL == 2 && VG <= 2) {
         if (p.cost_hi && !p.gate_bits && !(CV_DEV(p) & 0x10)) {
             hipLaunchKernelGGL((cv_v3_kernel<FeatT, CPL, FULL, 8, LPU, VG, NP | 64 | 0x2000>), grid, block, lds, stream, p);

@@ -57,8 +57,13 @@ if os.environ.get("ABLATE_PX2"):                       # round 5: two pixels per
             torch.cuda.synchronize()
             outs.append((hi.clone(), lo.clone()))
         print(f"{wl.name}: two-pixel batches bit-identical to the one-pixel loop: {torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])}")
+HALFQ = 0x80 << 8
+if os.environ.get("ABLATE_HALFQ"):                     # round 6: what the quad-form (mu, sigma) map's bytes cost cost_volume_v3.hip's product instance: the same map as 8 fp16 per
+    VARIANTS = [("production (fp32 quad form, 32 B)", 0), ("fp16 quad form, 16 B per candidate", HALFQ),   # entry (16-byte stride), one load per candidate; gates differ at the 1e-3 level
+                ("production, again", 0), ("fp16 quad form, again", HALFQ)]
 if os.environ.get("ABLATE_SHORT"):
     VARIANTS = VARIANTS[:2] if os.environ.get("ABLATE_TX") else [VARIANTS[0], VARIANTS[1], VARIANTS[5], VARIANTS[6]]
+_prod = None
 for name, path in VARIANTS:
     if split and (path & 0xff) == 3:
         continue
@@ -69,6 +74,17 @@ for name, path in VARIANTS:
         cv(ref_gmm=inp["ref_gmms"], k_list=k, **kw)
     except lib.MagnetError as e:
         print(f"{wl.name} {name}: {e}"); continue
+    if path & HALFQ and os.environ.get("ABLATE_HALFQ"):   # rewrite the packed map in place: entry e = 8 fp16 at byte 16 e (the front half of the buffer)
+        q16 = cv._gmm_quad.reshape(-1).to(torch.float16)
+        cv._gmm_quad.view(torch.float16).reshape(-1)[:q16.numel()] = q16
+        cv(ref_gmm=inp["ref_gmms"], k_list=k, **kw)
+        torch.cuda.synchronize()
+        if split and _prod is not None:                  # same amount of work: the cost channels differ where a gate flipped, nowhere else by more than rounding
+            a, b = hi[:, :wl.D].float(), _prod
+            print(f"   fp16 map vs fp32 map: {float((a != b).float().mean()):.4f} of the cost entries differ, {float(((a - b).abs() > 0.05 * b.abs().clamp_min(1.0)).float().mean()):.5f} by more than 5 %; "
+                  f"non-zero entries {float((a != 0).float().mean()):.4f} vs {float((b != 0).float().mean()):.4f}")
+    elif split and os.environ.get("ABLATE_HALFQ"):
+        torch.cuda.synchronize(); _prod = hi[:, :wl.D].float().clone()
     # the chip's clock / power state drifts for the first second of load (20-launch samples differed by 8 % between the first and
     # the last variant of one process): ~0.3 s of the same kernel first, then the median of 5 samples of 40 launches
     for _ in range(300):
