@@ -11,7 +11,7 @@ import shutil
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
 src, dst = os.path.join(R, "gpurun_out", tag), os.path.join(R, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
@@ -89,7 +89,7 @@ if st:
         w = csv.writer(o); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows[:16]:
             w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-for f in ("configs.jsonl", "ablate_C2_split.log", "ablate_tx.log", "issue_rate.txt", "gather_rate.txt", "bench_fnet.json",
+for f in ("configs.jsonl", "ablate_C2_split.log", "ablate_tx.log", "ablate_halfq.log", "clock_recovery.jsonl", "cu_partition_probe.jsonl", "issue_rate.txt", "gather_rate.txt", "bench_fnet.json",
           "fnet_layers.txt", "fvolume_bench.jsonl", "bench_end_to_end.json", "bench_pipeline.json", "kernel_only_C2_nchw.json", "parity_stats_gpu_tests.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f if f != "configs.jsonl" else "matcher_kernel_only_all_configs.jsonl"))

@@ -13,7 +13,7 @@
 #   ablate_*.log          matcher variants on the dev library (tools/ablate.py), issue_rate / gather_rate microbenchmarks
 # Every profiler pass has a short timeout: some TA/TCP/TD counter sets hang rocprofv3 on this pool.  The --pmc passes run the
 # contract's own 5 + 20 steps, so that the clock / busy counters describe the chip state the bench line was measured in.
-tag=${1:-r5}
+tag=${1:-r6}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$tag; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
@@ -56,8 +56,11 @@ timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fvolume_s
 timeout 200 python tools/bench_end_to_end.py > $O/bench_end_to_end.json 2> $O/bench_end_to_end.err
 timeout 200 python tools/bench_pipeline.py 2>/dev/null | tail -1 > $O/bench_pipeline.json
 # matcher variants (dev library) + instruction / gather microbenchmarks
-ABLATE_TX=1 timeout 150 python tools/ablate.py C2 64 split 2>&1 | grep -v amdgpu.ids > $O/ablate_C2_split.log
-for cfg in "C2L 4" "C4L 4" "shipped 64" "C1 64"; do set -- $cfg; ABLATE_TX=1 timeout 200 python tools/ablate.py $1 $2 split 2>&1 | grep -v amdgpu.ids >> $O/ablate_tx.log; done
+ABLATE_PX2=1 timeout 150 python tools/ablate.py C2 64 split 2>&1 | grep -v amdgpu.ids > $O/ablate_C2_split.log
+# round 6: the records that close the review's items (same box as the bench line above)
+ABLATE_HALFQ=1 timeout 200 python tools/ablate.py C2 64 split 2>&1 | grep -v amdgpu.ids > $O/ablate_halfq.log           # (mu, sigma) map bytes: fp16 map A/B
+timeout 300 python tools/clock_recovery.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|model = MAGNET" > $O/clock_recovery.jsonl      # matcher time vs idle gap behind matrix-core work
+timeout 600 python tools/cu_partition_probe.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|model = MAGNET" > $O/cu_partition_probe.jsonl   # step halves side by side on disjoint CU partitions
 for u in issue_rate gather_rate; do
   [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2>/dev/null
   timeout 120 tools/ubench/$u > $O/$u.txt 2>&1
