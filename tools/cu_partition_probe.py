@@ -85,10 +85,28 @@ def ms(t):
     return e0.elapsed_time(e1) / n
 
 
+# second question (PROBE_PACKS=1): only the HBM-bound layout packs of the NEXT batch on the small partition, matcher + convolutions of this
+# batch on the large one
+if os.environ.get("PROBE_PACKS"):
+    from magnet_amd.magnet import depth_sampling
+    cvm = CostVolumeCW(inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"], inp["is_valid"], inp["cam_intrins"], 5, feat_dtype="bf16")
+
+    def stage_a():                                           # the packs alone (features x 2, x_d3)
+        lib.pack_features(inp["ref_feat"], lib.feat_enum("bf16"), pad=0)
+        lib.pack_features(inp["nghbr_feat"], lib.feat_enum("bf16"), pad=1)
+        lib.pack_split(inp["x_d3"], gin2_hi, gin2_lo, ctot, Dp)
+
+    _conv_b = stage_b
+
+    def stage_b():                                           # quad-form map + matcher + both convolution launches
+        cvm._gmm_quad = None
+        cvm(ref_gmm=pred0, k_list=model.k_list, out_split=(gin_hi, gin_lo, ctot))
+        _conv_b()
+
 full = torch.cuda.Stream(device=dev)
 ta = timed(stage_a, full); torch.cuda.synchronize(); tb = timed(stage_b, full); torch.cuda.synchronize()
 print(json.dumps({"partition": "none (256 CUs each, one after the other)", "stage_a_ms": round(ms(ta), 3), "stage_b_ms": round(ms(tb), 3), "sum_ms": round(ms(ta) + ms(tb), 3)}), flush=True)
-for nb in (240, 224, 208, 192, 176, 160):
+for nb in ((248, 240, 232, 224, 208, 192) if os.environ.get("PROBE_PACKS") else (240, 224, 208, 192, 176, 160)):
     sb_, sa_ = masked_stream(0, nb), masked_stream(nb, 256)
     tb = timed(stage_b, sb_); torch.cuda.synchronize()
     ta = timed(stage_a, sa_, n=6, warm=2); torch.cuda.synchronize()
