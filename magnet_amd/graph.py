@@ -1,6 +1,7 @@
-"""HIP-graph replay of the refinement loop for small, launch-bound batches.
+"""HIP-graph replay of the refinement loop: the host leaves the loop.
 
-At 64 frames per step the path is GPU-bound (8.5 ms of kernels, ~13 launches).  The reference's own evaluation loop feeds ONE
+At 64 frames per step the path is GPU-bound (5.8 ms of kernels, ~15 device operations): replaying the captured step still saves the
+inter-operation gaps — 5.78 -> 5.69 ms per C2 step, same box (round 6; bench.py replays the step this way by default, --no-graph: eager).  The reference's own evaluation loop feeds ONE
 frame at a time (test_MaGNet.py:166-170, batch size 1).  `GraphedRefine` captures `MAGNET.match_and_refine` for a fixed shape
 into a HIP graph once (torch.cuda.CUDAGraph: our kernels are launched on torch's capture stream, so they are recorded like
 torch's own) and replays it per frame: one launch from the host's point of view.  Measured on MI355X (bench.py --frames 1
@@ -34,7 +35,9 @@ class GraphedRefine:
                 model.match_and_refine(*self.static, self.is_valid, self.cam, mode=mode)
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # thread-local capture mode: another thread of the process that polls events meanwhile (torch.distributed's RCCL watchdog, once
+        # a process group exists — bench.py always has one) must not invalidate this thread's capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             self.out = model.match_and_refine(*self.static, self.is_valid, self.cam, mode=mode)
 
     def __call__(self, ref_gmms, x_d3, ref_feat, nghbr_feat, nghbr_gmms, nghbr_poses, is_valid=None, cam_intrins=None):
