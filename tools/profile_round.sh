@@ -60,11 +60,29 @@ ABLATE_PX2=1 timeout 150 python tools/ablate.py C2 64 split 2>&1 | grep -v amdgp
 # round 6: the records that close the review's items (same box as the bench line above)
 ABLATE_HALFQ=1 timeout 200 python tools/ablate.py C2 64 split 2>&1 | grep -v amdgpu.ids > $O/ablate_halfq.log           # (mu, sigma) map bytes: fp16 map A/B
 timeout 300 python tools/clock_recovery.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|model = MAGNET" > $O/clock_recovery.jsonl      # matcher time vs idle gap behind matrix-core work
+# mask head on a side stream (same-box A/B + the kernel trace that shows the kernels serialise), frames-per-step sweep (launch quantisation: 256-row tiles over 256 CUs)
+B6="python bench.py --no-cpu-baseline --no-pmc --sustain-s 0 --no-graph"
+: > $O/overlap_ab.jsonl; for i in 1 2; do timeout 120 $B6 2>/dev/null | tail -1 >> $O/overlap_ab.jsonl; timeout 120 $B6 --overlap 2>/dev/null | tail -1 >> $O/overlap_ab.jsonl; done
+timeout 120 rocprofv3 --kernel-trace --output-format csv -d $O/overlap_trace -o t -- $B6 --overlap --steps 6 --warmup 3 > $O/overlap_trace.log 2>&1
+: > $O/frames_sweep.jsonl; for f in 60 62 63 64 66 68 64; do timeout 120 $B6 --frames $f 2>/dev/null | tail -1 >> $O/frames_sweep.jsonl; done
+: > $O/graph_replay_ab.jsonl; for i in 1 2 3; do timeout 120 python bench.py --no-cpu-baseline --no-pmc --sustain-s 0 2>/dev/null | tail -1 >> $O/graph_replay_ab.jsonl; timeout 120 $B6 2>/dev/null | tail -1 >> $O/graph_replay_ab.jsonl; done
+timeout 300 python tools/wino_bound.py 2>&1 | grep -v amdgpu.ids > $O/wino_bound.jsonl
 timeout 600 python tools/cu_partition_probe.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|model = MAGNET" > $O/cu_partition_probe.jsonl   # step halves side by side on disjoint CU partitions
+PROBE_PACKS=1 timeout 600 python tools/cu_partition_probe.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|model = MAGNET" > $O/cu_partition_probe_packs.jsonl   # only the packs on the small partition
 for u in issue_rate gather_rate; do
   [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2>/dev/null
   timeout 120 tools/ubench/$u > $O/$u.txt 2>&1
 done
 find $O -name "*.db" -delete; find $O -name "*_agent_info.csv" -delete
+for f in $(find $O/overlap_trace -name "*kernel_trace.csv"); do python - "$f" "$O/overlap_kernel_trace_tail.txt" <<'PY'
+import csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+t0 = int(rows[0]["Start_Timestamp"])
+keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_mfma", "cv_v3", "pack_", "upsample"))][-40:]
+with open(sys.argv[2], "w") as f:
+    for r in keep:
+        f.write(f'{(int(r["Start_Timestamp"]) - t0) / 1e3:12.1f} us  +{(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:9.1f} us  q{r.get("Queue_Id", "?")}  {r["Kernel_Name"][:90]}\n')
+PY
+done
 for f in $(find $O -name "*kernel_trace.csv"); do head -200 $f > $f.head; rm $f; done
 tail -1 $O/bench.json | cut -c1-600
