@@ -89,7 +89,7 @@ if st:
         w = csv.writer(o); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows[:16]:
             w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-for f in ("configs.jsonl", "ablate_C2_split.log", "ablate_tx.log", "ablate_halfq.log", "clock_recovery.jsonl", "cu_partition_probe.jsonl", "cu_partition_probe_packs.jsonl", "overlap_ab.jsonl", "overlap_kernel_trace_tail.txt", "frames_sweep.jsonl", "wino_bound.jsonl", "issue_rate.txt", "gather_rate.txt", "bench_fnet.json",
+for f in ("configs.jsonl", "ablate_C2_split.log", "ablate_tx.log", "ablate_halfq.log", "clock_recovery.jsonl", "cu_partition_probe.jsonl", "cu_partition_probe_packs.jsonl", "power_probe.jsonl", "overlap_ab.jsonl", "overlap_kernel_trace_tail.txt", "frames_sweep.jsonl", "wino_bound.jsonl", "issue_rate.txt", "gather_rate.txt", "bench_fnet.json",
           "fnet_layers.txt", "fvolume_bench.jsonl", "bench_end_to_end.json", "bench_pipeline.json", "kernel_only_C2_nchw.json", "parity_stats_gpu_tests.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f if f != "configs.jsonl" else "matcher_kernel_only_all_configs.jsonl"))

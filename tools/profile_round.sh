@@ -69,6 +69,7 @@ timeout 120 rocprofv3 --kernel-trace --output-format csv -d $O/overlap_trace -o 
 timeout 300 python tools/wino_bound.py 2>&1 | grep -v amdgpu.ids > $O/wino_bound.jsonl
 timeout 600 python tools/cu_partition_probe.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|model = MAGNET" > $O/cu_partition_probe.jsonl   # step halves side by side on disjoint CU partitions
 PROBE_PACKS=1 timeout 600 python tools/cu_partition_probe.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|model = MAGNET" > $O/cu_partition_probe_packs.jsonl   # only the packs on the small partition
+timeout 300 python tools/power_probe.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|model = MAGNET" > $O/power_probe.jsonl   # socket power / shader clock per part of the step (rocm-smi)
 for u in issue_rate gather_rate; do
   [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2>/dev/null
   timeout 120 tools/ubench/$u > $O/$u.txt 2>&1
