@@ -476,8 +476,11 @@ def main():
     # enough frames per step that one launch fills the chip and the working set exceeds the 256 MiB L3
     B = a.frames or max(1, min(16 if a.with_fnet else 64, int(round(1200e6 / max(wl.algorithmic_bytes(), 1)))))
     torch.manual_seed(1234)                               # every rank draws its own init; rank 0's wins below
-    model = MAGNET(make_args(wl, iters), d_net=_NoBackbone(), f_net=_NoBackbone(), feat_dtype=fdt,
-                   conv_backend=a.conv_backend)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.filterwarnings("ignore", message=r"MAGNET. args\.\w+_ckpt is not set")   # no backbones here: the bench starts from their outputs
+        model = MAGNET(make_args(wl, iters), d_net=_NoBackbone(), f_net=_NoBackbone(), feat_dtype=fdt,
+                       conv_backend=a.conv_backend)
     model_cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         import copy
