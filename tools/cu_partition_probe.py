@@ -106,8 +106,10 @@ if os.environ.get("PROBE_PACKS"):
 full = torch.cuda.Stream(device=dev)
 ta = timed(stage_a, full); torch.cuda.synchronize(); tb = timed(stage_b, full); torch.cuda.synchronize()
 print(json.dumps({"partition": "none (256 CUs each, one after the other)", "stage_a_ms": round(ms(ta), 3), "stage_b_ms": round(ms(tb), 3), "sum_ms": round(ms(ta) + ms(tb), 3)}), flush=True)
-for nb in ((248, 240, 232, 224, 208, 192) if os.environ.get("PROBE_PACKS") else (240, 224, 208, 192, 176, 160)):
-    sb_, sa_ = masked_stream(0, nb), masked_stream(nb, 256)
+# PROBE_FULL=1: both streams may use ALL 256 CUs (two separate hardware queues, no partition): what the dispatcher makes of the two kernels'
+# workgroups when nothing but CU resources keeps them apart
+for nb in ((256,) if os.environ.get("PROBE_FULL") else (248, 240, 232, 224, 208, 192) if os.environ.get("PROBE_PACKS") else (240, 224, 208, 192, 176, 160)):
+    sb_, sa_ = masked_stream(0, nb), masked_stream(nb if nb < 256 else 0, 256)
     tb = timed(stage_b, sb_); torch.cuda.synchronize()
     ta = timed(stage_a, sa_, n=6, warm=2); torch.cuda.synchronize()
     alone_a, alone_b = ms(ta), ms(tb)
