@@ -98,3 +98,21 @@ def test_dead_rank_at_world_size_8():
     assert dt < 10.0 + 25.0, f"launcher took {dt:.1f} s to give up"      # 8 python + torch start-ups on top of the 10 s bound
     assert "[bench launcher] rank 5 exited with 3" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_counter_children_inherit_the_parents_step_flags():
+    """bench.py's rocprofv3 counter children must run the configuration of the line they annotate (advisor, round 5): every flag that
+    changes what a step executes is forwarded; they never create a process group and never replay a graph (counters per dispatch)."""
+    import argparse
+    import bench
+    a = argparse.Namespace(workload="C4", frames=12, iters=2, feat_dtype="fp32", path=2, conv_backend="torch", no_fuse_tail=True,
+                           no_fuse_upsample=False, graph=False, overlap=True, overlap_pack=False, packed_inputs=True, with_fnet=False,
+                           dev_lib=True, kernel_only=False, nchw_out=False)
+    args = bench._step_child_args(a, steps=2, warmup=1)
+    for flag, val in (("--workload", "C4"), ("--frames", "12"), ("--iters", "2"), ("--feat-dtype", "fp32"), ("--path", "2"),
+                      ("--conv-backend", "torch"), ("--steps", "2"), ("--warmup", "1")):
+        assert args[args.index(flag) + 1] == val, (flag, args)
+    for flag in ("--no-fuse-tail", "--overlap", "--packed-inputs", "--dev-lib", "--no-group", "--no-graph"):
+        assert flag in args, (flag, args)
+    for flag in ("--no-fuse-upsample", "--overlap-pack", "--with-fnet", "--kernel-only", "--nchw-out", "--gpus"):
+        assert flag not in args, (flag, args)
