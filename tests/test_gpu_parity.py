@@ -442,6 +442,16 @@ def test_full_step_bench_size_batch_invariance(hip_lib, gpu):
             again = model.match_and_refine(inp["ref_gmms"], x_d3, inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"],
                                            inp["is_valid"], inp["cam_intrins"], mode="test")[-1]
             assert torch.equal(again, full)
+    # what bench.py times since round 6: the same step captured once and REPLAYED as a HIP graph (magnet_amd/graph.py) — bit-identical
+    # to the eager step at the contract's batch, on the first replay and on a later one
+    from magnet_amd.graph import GraphedRefine
+    g = GraphedRefine(model, inp["ref_gmms"], x_d3, inp["ref_feat"], inp["nghbr_feat"], inp["nghbr_gmms"], inp["nghbr_poses"],
+                      inp["is_valid"], inp["cam_intrins"], mode="test")
+    for _ in range(3):
+        rep = g(*g.static)[-1]
+        torch.cuda.synchronize()
+        assert torch.equal(rep, full), "graph replay differs from the eager step"
+    del g
     V = wl.V
     for b in (0, 63):
         sel = lambda t: t[b:b + 1].contiguous()
